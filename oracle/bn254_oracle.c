@@ -1,0 +1,1085 @@
+/* bn254_oracle.c -- CPU oracle for the BLS-BN254 verification path.  TEST INFRASTRUCTURE ONLY.
+ * See bn254_oracle.h for scope and parity status (PINNED against the reference's golden vectors).
+ *
+ * Restates, in plain C (gcc, unsigned __int128), the algorithm of mikelodder7/bls-bn254.  Reference
+ * files followed (all under /root/reference/src/inner_types/, read as a specification):
+ *   fp.rs     :115-122 from_okm, :164-168 sgn0, :207-243 invert/sqrt_ratio, :284-371 SVDW map,
+ *             :428-458 is_square/hash/encode
+ *   fp2.rs    :95-99 sgn0, :161-218 invert/sqrt, :221-287 SVDW map, :377-402 mul/square,
+ *             :441-487 is_square/hash/encode
+ *   fp6.rs    :123-152 mul_by_1/mul_by_01/mul_by_non_residue, :225-242 multiply
+ *   fp12.rs   :131-137 conjugate, :170-219 square/multiply/invert
+ *   g1.rs     :297-302,:339-360 codecs, :704-841 complete add/double/multiply, :910-928 hash/encode
+ *   g2.rs     :292-300,:350-388 codecs, :685-693 clear_cofactor, :749-886 add/double/multiply,
+ *             :919-954 hash/encode/psi
+ *   pairings.rs :52-115 fp4_square/cyclotomic_square, :499-579 Gt byte layout,
+ *             :760-857 pairing/multi_miller_loop identity handling, :901-962 doubling/addition step
+ *   scalar.rs :523-548 Fr arithmetic (big-endian both ways; E11 not reproduced)
+ * Third-party arithmetic the reference delegates to (crypto-bigint 0.5.5, ff 0.13.1, sha2 0.10.8,
+ * elliptic-curve 0.13.8 hash2curve) has mathematically fixed semantics and is restated here
+ * (Montgomery 4x64 limbs; FIPS 180-4 SHA-256; RFC 9380 5.3.1 expand_message_xmd).
+ *
+ * Errata NOT reproduced: E1-E7 (the tower is built on xi = 9+u, the Miller
+ * loop is the BN optimal ate over NAF(6x+2) with the two Frobenius line additions, the sparse
+ * multiply is "034", the final exponent is the BN one pinned by Gt::generator()), E9, E10 (strict
+ * canonical decoding), E12, E15 (inv0(0) = 0), and the Fp6 inverse denominator (fp6.rs:280 pairs
+ * c1*c1 + c2*c2; the correct a1*c2 + a2*c1 is used).
+ */
+#include "bn254_oracle.h"
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+
+static __thread u64 cnt_mul, cnt_sqr;
+void oracle_counters_reset(void) { cnt_mul = cnt_sqr = 0; }
+void oracle_counters_get(u64* m, u64* s) { *m = cnt_mul; *s = cnt_sqr; }
+
+/* ------------------------------------------------------------------ 256-bit Montgomery arithmetic */
+typedef struct { u64 m[4]; u64 ninv; u64 r1[4]; u64 r2[4]; } modctx;
+
+static int ge256(const u64 a[4], const u64 b[4]) {
+  for (int i = 3; i >= 0; --i) { if (a[i] != b[i]) return a[i] > b[i]; }
+  return 1;
+}
+static u64 sub256(u64 r[4], const u64 a[4], const u64 b[4]) {
+  u64 br = 0;
+  for (int i = 0; i < 4; ++i) { u128 d = (u128)a[i] - b[i] - br; r[i] = (u64)d; br = (u64)(d >> 64) & 1; }
+  return br;
+}
+static u64 add256(u64 r[4], const u64 a[4], const u64 b[4]) {
+  u128 c = 0;
+  for (int i = 0; i < 4; ++i) { c += (u128)a[i] + b[i]; r[i] = (u64)c; c >>= 64; }
+  return (u64)c;
+}
+static void mod_add(u64 r[4], const u64 a[4], const u64 b[4], const modctx* M) {
+  u64 c = add256(r, a, b);
+  if (c || ge256(r, M->m)) sub256(r, r, M->m);
+}
+static void mod_sub(u64 r[4], const u64 a[4], const u64 b[4], const modctx* M) {
+  if (sub256(r, a, b)) add256(r, r, M->m);
+}
+static void mont_mul(u64 r[4], const u64 a[4], const u64 b[4], const modctx* M) {
+  u64 t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {
+    u128 c = 0;
+    for (int j = 0; j < 4; ++j) { c += (u128)a[j] * b[i] + t[j]; t[j] = (u64)c; c >>= 64; }
+    c += t[4]; t[4] = (u64)c; t[5] = (u64)(c >> 64);
+    u64 m = t[0] * M->ninv;
+    c = (u128)m * M->m[0] + t[0]; c >>= 64;
+    for (int j = 1; j < 4; ++j) { c += (u128)m * M->m[j] + t[j]; t[j - 1] = (u64)c; c >>= 64; }
+    c += t[4]; t[3] = (u64)c; t[4] = t[5] + (u64)(c >> 64);
+  }
+  if (t[4] || ge256(t, M->m)) sub256(r, t, M->m); else memcpy(r, t, 32);
+}
+static void modctx_init(modctx* M, const u64 m[4]) {
+  memcpy(M->m, m, 32);
+  u64 inv = 1;                                   /* Newton: inv = m^-1 mod 2^64 */
+  for (int i = 0; i < 6; ++i) inv *= 2 - m[0] * inv;
+  M->ninv = (u64)0 - inv;
+  u64 x[4] = {1, 0, 0, 0};
+  for (int i = 0; i < 512; ++i) {
+    mod_add(x, x, x, M);
+    if (i == 255) memcpy(M->r1, x, 32);
+  }
+  memcpy(M->r2, x, 32);
+}
+static void be32_to_limbs(u64 l[4], const uint8_t b[32]) {
+  for (int i = 0; i < 4; ++i) {
+    u64 v = 0;
+    for (int j = 0; j < 8; ++j) v = (v << 8) | b[8 * (3 - i) + j];
+    l[i] = v;
+  }
+}
+static void limbs_to_be32(uint8_t b[32], const u64 l[4]) {
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 8; ++j) b[8 * (3 - i) + j] = (uint8_t)(l[i] >> (8 * (7 - j)));
+}
+
+static modctx FP, FR;
+static const u64 P_LIMBS[4] = {0x3c208c16d87cfd47ULL, 0x97816a916871ca8dULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+static const u64 R_LIMBS[4] = {0x43e1f593f0000001ULL, 0x2833e84879b97091ULL, 0xb85045b68181585dULL, 0x30644e72e131a029ULL};
+#define BN_X 0x44e992b44a6909f1ULL
+
+/* ------------------------------------------------------------------ Fp */
+typedef struct { u64 l[4]; } fp;
+static fp FP_ZERO, FP_ONE;
+
+static inline fp fp_add(fp a, fp b) { fp r; mod_add(r.l, a.l, b.l, &FP); return r; }
+static inline fp fp_sub(fp a, fp b) { fp r; mod_sub(r.l, a.l, b.l, &FP); return r; }
+static inline fp fp_neg(fp a) { return fp_sub(FP_ZERO, a); }
+static inline fp fp_dbl(fp a) { return fp_add(a, a); }
+static inline fp fp_mul(fp a, fp b) { fp r; ++cnt_mul; mont_mul(r.l, a.l, b.l, &FP); return r; }
+static inline fp fp_sqr(fp a) { fp r; ++cnt_sqr; mont_mul(r.l, a.l, a.l, &FP); return r; }
+static inline int fp_eq(fp a, fp b) { return memcmp(a.l, b.l, 32) == 0; }
+static inline int fp_is_zero(fp a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+static fp fp_from_u64(u64 v) { fp t = {{v, 0, 0, 0}}, r; mont_mul(r.l, t.l, FP.r2, &FP); return r; }
+static void fp_canon(u64 out[4], fp a) { static const u64 one[4] = {1, 0, 0, 0}; mont_mul(out, a.l, one, &FP); }
+static int fp_from_be(fp* r, const uint8_t b[32]) {      /* PrimeField::from_repr fp.rs:249-254 */
+  u64 t[4]; be32_to_limbs(t, b);
+  if (ge256(t, FP.m)) return 0;
+  mont_mul(r->l, t, FP.r2, &FP); return 1;
+}
+static void fp_to_be(uint8_t b[32], fp a) { u64 t[4]; fp_canon(t, a); limbs_to_be32(b, t); }
+static fp fp_pow(fp a, const u64 e[4]) {
+  fp r = FP_ONE; int started = 0;
+  for (int i = 255; i >= 0; --i) {
+    if (started) r = fp_sqr(r);
+    if ((e[i / 64] >> (i % 64)) & 1) { r = started ? fp_mul(r, a) : a; started = 1; }
+  }
+  return r;
+}
+static u64 EXP_PM2[4], EXP_PM1_2[4], EXP_PP1_4[4], EXP_PM3_4[4], EXP_PM1_6[4], EXP_RM2[4];
+static fp fp_inv(fp a) { return fp_pow(a, EXP_PM2); }                      /* inv0: 0 -> 0 */
+static int fp_is_square(fp a) { fp t = fp_pow(a, EXP_PM1_2); return fp_is_zero(t) || fp_eq(t, FP_ONE); }
+static int fp_sqrt(fp* r, fp a) { fp y = fp_pow(a, EXP_PP1_4); *r = y; return fp_eq(fp_sqr(y), a); }
+static int fp_sgn0(fp a) { u64 t[4]; fp_canon(t, a); return (int)(t[0] & 1); }
+/* 48 big-endian bytes mod p (FromOkm, fp.rs:115-122) */
+static fp fp_from_okm(const uint8_t okm[48]) {
+  uint8_t hi[32]; memset(hi, 0, 16); memcpy(hi + 16, okm, 16);
+  u64 h[4], l[4]; be32_to_limbs(h, hi); be32_to_limbs(l, okm + 16);
+  fp H, L; mont_mul(H.l, h, FP.r2, &FP); mont_mul(H.l, H.l, FP.r2, &FP);   /* hi * 2^256 */
+  mont_mul(L.l, l, FP.r2, &FP);
+  return fp_add(H, L);
+}
+
+/* ------------------------------------------------------------------ Fp2 = Fp[u]/(u^2+1) */
+typedef struct { fp c0, c1; } fp2;
+static fp2 F2_ZERO, F2_ONE;
+static inline fp2 f2_add(fp2 a, fp2 b) { fp2 r = {fp_add(a.c0, b.c0), fp_add(a.c1, b.c1)}; return r; }
+static inline fp2 f2_sub(fp2 a, fp2 b) { fp2 r = {fp_sub(a.c0, b.c0), fp_sub(a.c1, b.c1)}; return r; }
+static inline fp2 f2_neg(fp2 a) { fp2 r = {fp_neg(a.c0), fp_neg(a.c1)}; return r; }
+static inline fp2 f2_dbl(fp2 a) { return f2_add(a, a); }
+static inline fp2 f2_conj(fp2 a) { fp2 r = {a.c0, fp_neg(a.c1)}; return r; }
+static inline int f2_eq(fp2 a, fp2 b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
+static inline int f2_is_zero(fp2 a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
+static fp2 f2_mul(fp2 a, fp2 b) {                 /* Karatsuba; same value as fp2.rs:377-390 */
+  fp t0 = fp_mul(a.c0, b.c0), t1 = fp_mul(a.c1, b.c1);
+  fp t2 = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
+  fp2 r = {fp_sub(t0, t1), fp_sub(fp_sub(t2, t0), t1)};
+  return r;
+}
+static fp2 f2_sqr(fp2 a) {                        /* fp2.rs:392-402 */
+  fp2 r = {fp_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1)), fp_dbl(fp_mul(a.c0, a.c1))};
+  return r;
+}
+static fp2 f2_mul_fp(fp2 a, fp s) { fp2 r = {fp_mul(a.c0, s), fp_mul(a.c1, s)}; return r; }
+static fp2 f2_mul_xi(fp2 a) {                     /* (9+u)(a+bu) = (9a-b) + (a+9b)u   (E1 fixed) */
+  fp a2 = fp_dbl(a.c0), a4 = fp_dbl(a2), a8 = fp_dbl(a4);
+  fp b2 = fp_dbl(a.c1), b4 = fp_dbl(b2), b8 = fp_dbl(b4);
+  fp2 r = {fp_sub(fp_add(a8, a.c0), a.c1), fp_add(fp_add(b8, a.c1), a.c0)};
+  return r;
+}
+static fp2 f2_inv(fp2 a) {                        /* fp2.rs:161-166 */
+  fp t = fp_inv(fp_add(fp_sqr(a.c0), fp_sqr(a.c1)));
+  fp2 r = {fp_mul(a.c0, t), fp_neg(fp_mul(a.c1, t))};
+  return r;
+}
+static fp2 f2_pow(fp2 a, const u64 e[4]) {
+  fp2 r = F2_ONE;
+  for (int i = 255; i >= 0; --i) { r = f2_sqr(r); if ((e[i / 64] >> (i % 64)) & 1) r = f2_mul(r, a); }
+  return r;
+}
+static int f2_is_square(fp2 a) { return fp_is_square(fp_add(fp_sqr(a.c0), fp_sqr(a.c1))); } /* fp2.rs:441-452 */
+static int f2_sgn0(fp2 a) {                       /* fp2.rs:95-99 */
+  int s0 = fp_sgn0(a.c0), z0 = fp_is_zero(a.c0), s1 = fp_sgn0(a.c1);
+  return s0 | (z0 & s1);
+}
+static int f2_sqrt(fp2* out, fp2 a) {             /* Algorithm 9 of eprint 2012/685, fp2.rs:172-218 */
+  if (f2_is_zero(a)) { *out = F2_ZERO; return 1; }
+  fp2 a1 = f2_pow(a, EXP_PM3_4);
+  fp2 alpha = f2_mul(f2_sqr(a1), a);
+  fp2 x0 = f2_mul(a1, a);
+  fp2 r;
+  if (f2_eq(alpha, f2_neg(F2_ONE))) { r.c0 = fp_neg(x0.c1); r.c1 = x0.c0; }
+  else r = f2_mul(f2_pow(f2_add(alpha, F2_ONE), EXP_PM1_2), x0);
+  *out = r;
+  return f2_eq(f2_sqr(r), a);
+}
+
+/* ------------------------------------------------------------------ Fp6 = Fp2[v]/(v^3 - xi) */
+typedef struct { fp2 c0, c1, c2; } fp6;
+static fp6 F6_ZERO, F6_ONE;
+static fp6 f6_add(fp6 a, fp6 b) { fp6 r = {f2_add(a.c0, b.c0), f2_add(a.c1, b.c1), f2_add(a.c2, b.c2)}; return r; }
+static fp6 f6_sub(fp6 a, fp6 b) { fp6 r = {f2_sub(a.c0, b.c0), f2_sub(a.c1, b.c1), f2_sub(a.c2, b.c2)}; return r; }
+static fp6 f6_neg(fp6 a) { fp6 r = {f2_neg(a.c0), f2_neg(a.c1), f2_neg(a.c2)}; return r; }
+static int f6_eq(fp6 a, fp6 b) { return f2_eq(a.c0, b.c0) && f2_eq(a.c1, b.c1) && f2_eq(a.c2, b.c2); }
+static fp6 f6_mul_v(fp6 a) { fp6 r = {f2_mul_xi(a.c2), a.c0, a.c1}; return r; }          /* fp6.rs:146-152 */
+static fp6 f6_mul(fp6 a, fp6 b) {                  /* fp6.rs:225-242 */
+  fp2 aa = f2_mul(a.c0, b.c0), bb = f2_mul(a.c1, b.c1), cc = f2_mul(a.c2, b.c2);
+  fp2 t0 = f2_sub(f2_sub(f2_mul(f2_add(a.c1, a.c2), f2_add(b.c1, b.c2)), bb), cc);
+  fp2 t1 = f2_sub(f2_sub(f2_mul(f2_add(a.c0, a.c1), f2_add(b.c0, b.c1)), aa), bb);
+  fp2 t2 = f2_sub(f2_sub(f2_mul(f2_add(a.c0, a.c2), f2_add(b.c0, b.c2)), aa), cc);
+  fp6 r = {f2_add(aa, f2_mul_xi(t0)), f2_add(t1, f2_mul_xi(cc)), f2_add(t2, bb)};
+  return r;
+}
+static fp6 f6_sqr(fp6 a) { return f6_mul(a, a); }
+static fp6 f6_mul_fp2(fp6 a, fp2 s) { fp6 r = {f2_mul(a.c0, s), f2_mul(a.c1, s), f2_mul(a.c2, s)}; return r; }
+static fp6 f6_mul_by_01(fp6 a, fp2 c0, fp2 c1) {   /* fp6.rs:131-144 */
+  fp2 aa = f2_mul(a.c0, c0), bb = f2_mul(a.c1, c1);
+  fp2 t1 = f2_add(f2_mul_xi(f2_mul(a.c2, c1)), aa);
+  fp2 t2 = f2_sub(f2_sub(f2_mul(f2_add(c0, c1), f2_add(a.c0, a.c1)), aa), bb);
+  fp2 t3 = f2_add(f2_mul(a.c2, c0), bb);
+  fp6 r = {t1, t2, t3};
+  return r;
+}
+static fp6 f6_inv(fp6 a) {                          /* fp6.rs:261-287 with the denominator corrected */
+  fp2 c0 = f2_sub(f2_sqr(a.c0), f2_mul_xi(f2_mul(a.c1, a.c2)));
+  fp2 c1 = f2_sub(f2_mul_xi(f2_sqr(a.c2)), f2_mul(a.c0, a.c1));
+  fp2 c2 = f2_sub(f2_sqr(a.c1), f2_mul(a.c0, a.c2));
+  fp2 t = f2_add(f2_mul(a.c0, c0), f2_mul_xi(f2_add(f2_mul(a.c2, c1), f2_mul(a.c1, c2))));
+  t = f2_inv(t);
+  fp6 r = {f2_mul(c0, t), f2_mul(c1, t), f2_mul(c2, t)};
+  return r;
+}
+
+/* ------------------------------------------------------------------ Fp12 = Fp6[w]/(w^2 - v) */
+typedef struct { fp6 c0, c1; } fp12;
+static fp12 F12_ONE;
+static fp2 GAMMA[4][6];   /* GAMMA[k][i] = xi^(i (p^k - 1)/6), k = 1..3 */
+
+static int f12_eq(fp12 a, fp12 b) { return f6_eq(a.c0, b.c0) && f6_eq(a.c1, b.c1); }
+static fp12 f12_mul(fp12 a, fp12 b) {               /* fp12.rs:203-210 */
+  fp6 aa = f6_mul(a.c0, b.c0), bb = f6_mul(a.c1, b.c1);
+  fp6 t = f6_mul(f6_add(a.c0, a.c1), f6_add(b.c0, b.c1));
+  fp12 r = {f6_add(aa, f6_mul_v(bb)), f6_sub(f6_sub(t, aa), bb)};
+  return r;
+}
+static fp12 f12_sqr(fp12 a) {                       /* complex squaring, fp12.rs:170-180 */
+  fp6 ab = f6_mul(a.c0, a.c1);
+  fp6 c0c1 = f6_add(a.c0, a.c1);
+  fp6 c0 = f6_add(f6_mul_v(a.c1), a.c0);
+  c0 = f6_mul(c0, c0c1);
+  c0 = f6_sub(c0, ab);
+  fp12 r;
+  r.c1 = f6_add(ab, ab);
+  r.c0 = f6_sub(c0, f6_mul_v(ab));
+  return r;
+}
+static fp12 f12_conj(fp12 a) { fp12 r = {a.c0, f6_neg(a.c1)}; return r; }                /* fp12.rs:131-137 */
+static fp12 f12_inv(fp12 a) {                       /* fp12.rs:212-219 */
+  fp6 t = f6_inv(f6_sub(f6_sqr(a.c0), f6_mul_v(f6_sqr(a.c1))));
+  fp12 r = {f6_mul(a.c0, t), f6_neg(f6_mul(a.c1, t))};
+  return r;
+}
+/* w-basis index of tower slot: c0.c0=w^0 c0.c1=w^2 c0.c2=w^4 c1.c0=w^1 c1.c1=w^3 c1.c2=w^5 */
+static fp12 f12_frob(fp12 a, int k) {               /* E3 fixed: coefficients are xi^(i(p^k-1)/6) */
+  fp2* s[6] = {&a.c0.c0, &a.c1.c0, &a.c0.c1, &a.c1.c1, &a.c0.c2, &a.c1.c2};   /* w^0..w^5 */
+  for (int i = 0; i < 6; ++i) {
+    fp2 c = *s[i];
+    if (k & 1) c = f2_conj(c);
+    if (i) c = f2_mul(c, GAMMA[k][i]);
+    *s[i] = c;
+  }
+  return a;
+}
+/* f * (o0 + o3 w + o4 w^3): the D-type sparse multiply (E7: "034", not "014") */
+static fp12 f12_mul_by_034(fp12 f, fp2 o0, fp2 o3, fp2 o4) {
+  fp6 a = f6_mul_fp2(f.c0, o0);
+  fp6 b = f6_mul_by_01(f.c1, o3, o4);
+  fp6 e = f6_mul_by_01(f6_add(f.c0, f.c1), f2_add(o0, o3), o4);
+  fp12 r;
+  r.c1 = f6_sub(f6_sub(e, a), b);
+  r.c0 = f6_add(a, f6_mul_v(b));
+  return r;
+}
+static void fp4_square(fp2* c0, fp2* c1, fp2 a, fp2 b) {         /* pairings.rs:52-63 */
+  fp2 t0 = f2_sqr(a), t1 = f2_sqr(b);
+  *c0 = f2_add(f2_mul_xi(t1), t0);
+  *c1 = f2_sub(f2_sub(f2_sqr(f2_add(a, b)), t0), t1);
+}
+static fp12 f12_cyclotomic_sqr(fp12 f) {                           /* pairings.rs:68-115 */
+  fp2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
+  fp2 t0, t1, t2, t3;
+  fp4_square(&t0, &t1, z0, z1);
+  z0 = f2_sub(t0, z0); z0 = f2_add(f2_add(z0, z0), t0);
+  z1 = f2_add(t1, z1); z1 = f2_add(f2_add(z1, z1), t1);
+  fp4_square(&t0, &t1, z2, z3);
+  fp4_square(&t2, &t3, z4, z5);
+  z4 = f2_sub(t0, z4); z4 = f2_add(f2_add(z4, z4), t0);
+  z5 = f2_add(t1, z5); z5 = f2_add(f2_add(z5, z5), t1);
+  t0 = f2_mul_xi(t3);
+  z2 = f2_add(t0, z2); z2 = f2_add(f2_add(z2, z2), t0);
+  z3 = f2_sub(t2, z3); z3 = f2_add(f2_add(z3, z3), t2);
+  fp12 r = {{z0, z4, z3}, {z2, z1, z5}};
+  return r;
+}
+static fp12 f12_cyclotomic_exp_x(fp12 f) {          /* f^x, x > 0 (E5: no conjugate) */
+  fp12 r = f;
+  for (int i = 61; i >= 0; --i) {                   /* x has 63 bits; top bit consumed by r = f */
+    r = f12_cyclotomic_sqr(r);
+    if ((BN_X >> i) & 1) r = f12_mul(r, f);
+  }
+  return r;
+}
+static fp12 final_exponentiation(fp12 f) {
+  /* easy part: f^((p^6-1)(p^2+1)) */
+  fp12 t = f12_mul(f12_conj(f), f12_inv(f));
+  t = f12_mul(f12_frob(t, 2), t);
+  /* hard part (Fuentes-Castaneda et al.), exponent l0 + l1 p + l2 p^2 + l3 p^3 with
+     l3 = 12x^3+6x^2+4x-1, l2 = 12x^3+6x^2+6x, l1 = 12x^3+6x^2+4x, l0 = 12x^3+12x^2+6x+1 */
+  fp12 a = f12_conj(f12_cyclotomic_exp_x(t));            /* t^-x  */
+  a = f12_cyclotomic_sqr(a);                             /* t^-2x */
+  fp12 b = f12_cyclotomic_sqr(a);                        /* t^-4x */
+  b = f12_mul(a, b);                                     /* t^-6x */
+  fp12 c = f12_conj(f12_cyclotomic_exp_x(b));            /* t^(6x^2) */
+  fp12 d = f12_conj(b);                                  /* t^(6x) */
+  b = f12_mul(c, d);                                     /* t^(6x^2+6x) */
+  d = f12_cyclotomic_sqr(c);                             /* t^(12x^2) */
+  fp12 e = f12_cyclotomic_exp_x(d);                      /* t^(12x^3) */
+  e = f12_mul(b, e);                                     /* t^(12x^3+6x^2+6x) = l2 */
+  d = f12_mul(a, e);                                     /* t^(12x^3+6x^2+4x) = l1 */
+  a = f12_mul(c, e);                                     /* t^(12x^3+12x^2+6x) */
+  c = f12_mul(t, a);                                     /* l0 */
+  a = f12_mul(c, f12_frob(d, 1));
+  a = f12_mul(a, f12_frob(e, 2));
+  c = f12_mul(f12_conj(t), d);                           /* l3 */
+  a = f12_mul(a, f12_frob(c, 3));
+  return a;
+}
+static void f12_to_bytes(uint8_t out[384], fp12 a) {     /* Gt::to_repr, pairings.rs:499-514 */
+  const fp2* s[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
+  for (int i = 0; i < 6; ++i) { fp_to_be(out + 64 * i, s[i]->c0); fp_to_be(out + 64 * i + 32, s[i]->c1); }
+}
+static int f12_from_bytes(fp12* a, const uint8_t in[384]) {   /* Gt::from_repr, pairings.rs:516-579 */
+  fp2* s[6] = {&a->c0.c0, &a->c0.c1, &a->c0.c2, &a->c1.c0, &a->c1.c1, &a->c1.c2};
+  for (int i = 0; i < 6; ++i)
+    if (!fp_from_be(&s[i]->c0, in + 64 * i) || !fp_from_be(&s[i]->c1, in + 64 * i + 32)) return 0;
+  return 1;
+}
+
+/* ------------------------------------------------------------------ G1: y^2 = x^3 + 3 */
+typedef struct { fp x, y; int inf; } g1a;
+typedef struct { fp x, y, z; } g1p;            /* homogeneous projective; identity = (0,1,0) */
+static fp FP_B, FP_B3;
+
+static g1p g1_identity(void) { g1p r = {FP_ZERO, FP_ONE, FP_ZERO}; return r; }
+static g1p g1_from_affine(g1a a) { if (a.inf) return g1_identity(); g1p r = {a.x, a.y, FP_ONE}; return r; }
+static g1a g1_to_affine(g1p p) {
+  g1a r;
+  if (fp_is_zero(p.z)) { r.x = FP_ZERO; r.y = FP_ONE; r.inf = 1; return r; }
+  fp zi = fp_inv(p.z); r.x = fp_mul(p.x, zi); r.y = fp_mul(p.y, zi); r.inf = 0; return r;
+}
+static fp fp_mul_b3(fp a) { fp a2 = fp_dbl(a), a4 = fp_dbl(a2), a8 = fp_dbl(a4); return fp_add(a8, a); }   /* fp.rs:414 */
+static g1p g1_add(g1p a, g1p b) {                 /* RCB 2015/1060 Alg 7, g1.rs:744-786 */
+  fp t0 = fp_mul(a.x, b.x), t1 = fp_mul(a.y, b.y), t2 = fp_mul(a.z, b.z);
+  fp t3 = fp_mul(fp_add(a.x, a.y), fp_add(b.x, b.y)); t3 = fp_sub(t3, fp_add(t0, t1));
+  fp t4 = fp_mul(fp_add(a.y, a.z), fp_add(b.y, b.z)); t4 = fp_sub(t4, fp_add(t1, t2));
+  fp y3 = fp_mul(fp_add(a.x, a.z), fp_add(b.x, b.z)); y3 = fp_sub(y3, fp_add(t0, t2));
+  fp x3 = fp_add(t0, t0); t0 = fp_add(x3, t0);
+  t2 = fp_mul_b3(t2);
+  fp z3 = fp_add(t1, t2); t1 = fp_sub(t1, t2);
+  y3 = fp_mul_b3(y3);
+  x3 = fp_mul(t4, y3); t2 = fp_mul(t3, t1); x3 = fp_sub(t2, x3);
+  y3 = fp_mul(y3, t0); t1 = fp_mul(t1, z3); y3 = fp_add(t1, y3);
+  t0 = fp_mul(t0, t3); z3 = fp_mul(z3, t4); z3 = fp_add(z3, t0);
+  g1p r = {x3, y3, z3};
+  return r;
+}
+static g1p g1_dbl(g1p a) {                        /* RCB Alg 9, g1.rs:788-818 */
+  fp t0 = fp_sqr(a.y);
+  fp z3 = fp_dbl(fp_dbl(fp_dbl(t0)));
+  fp t1 = fp_mul(a.y, a.z);
+  fp t2 = fp_mul_b3(fp_sqr(a.z));
+  fp x3 = fp_mul(t2, z3);
+  fp y3 = fp_add(t0, t2);
+  z3 = fp_mul(t1, z3);
+  t1 = fp_dbl(t2); t2 = fp_add(t1, t2);
+  t0 = fp_sub(t0, t2);
+  y3 = fp_add(x3, fp_mul(t0, y3));
+  t1 = fp_mul(a.x, a.y);
+  x3 = fp_dbl(fp_mul(t0, t1));
+  g1p r = {x3, y3, z3};
+  return r;
+}
+static g1p g1_mul_limbs(g1p p, const u64 k[4]) {  /* double-and-add, g1.rs:821-841 */
+  g1p acc = g1_identity();
+  for (int i = 255; i >= 0; --i) {
+    acc = g1_dbl(acc);
+    if ((k[i / 64] >> (i % 64)) & 1) acc = g1_add(acc, p);
+  }
+  return acc;
+}
+static int g1_on_curve_affine(g1a a) {            /* g1.rs:383-391 */
+  if (a.inf) return 1;
+  return fp_eq(fp_sqr(a.y), fp_add(fp_mul(fp_sqr(a.x), a.x), FP_B));
+}
+/* strict decoder: canonical coordinates; x == 0 -> identity (g1.rs:352-353); no on-curve check (E10) */
+static int g1_decode(g1a* r, const uint8_t b[64]) {
+  if (!fp_from_be(&r->x, b)) return 0;
+  if (fp_is_zero(r->x)) { r->y = FP_ONE; r->inf = 1; return 1; }
+  if (!fp_from_be(&r->y, b + 32)) return 0;
+  r->inf = 0; return 1;
+}
+static void g1_encode(uint8_t b[64], g1a a) {     /* g1.rs:297-302; identity = (0,1) g1.rs:265-271 */
+  if (a.inf) { a.x = FP_ZERO; a.y = FP_ONE; }
+  fp_to_be(b, a.x); fp_to_be(b + 32, a.y);
+}
+
+/* ------------------------------------------------------------------ G2: y^2 = x^3 + 3/(9+u) */
+typedef struct { fp2 x, y; int inf; } g2a;
+typedef struct { fp2 x, y, z; } g2p;
+static fp2 F2_B, F2_B3, PSI_X, PSI_Y;
+static g2a G2_GEN;
+
+static g2p g2_identity(void) { g2p r = {F2_ZERO, F2_ONE, F2_ZERO}; return r; }
+static g2p g2_from_affine(g2a a) { if (a.inf) return g2_identity(); g2p r = {a.x, a.y, F2_ONE}; return r; }
+static g2a g2_to_affine(g2p p) {
+  g2a r;
+  if (f2_is_zero(p.z)) { r.x = F2_ZERO; r.y = F2_ONE; r.inf = 1; return r; }
+  fp2 zi = f2_inv(p.z); r.x = f2_mul(p.x, zi); r.y = f2_mul(p.y, zi); r.inf = 0; return r;
+}
+static g2p g2_add(g2p a, g2p b) {                 /* RCB Alg 7, g2.rs:789-831 */
+  fp2 t0 = f2_mul(a.x, b.x), t1 = f2_mul(a.y, b.y), t2 = f2_mul(a.z, b.z);
+  fp2 t3 = f2_mul(f2_add(a.x, a.y), f2_add(b.x, b.y)); t3 = f2_sub(t3, f2_add(t0, t1));
+  fp2 t4 = f2_mul(f2_add(a.y, a.z), f2_add(b.y, b.z)); t4 = f2_sub(t4, f2_add(t1, t2));
+  fp2 y3 = f2_mul(f2_add(a.x, a.z), f2_add(b.x, b.z)); y3 = f2_sub(y3, f2_add(t0, t2));
+  fp2 x3 = f2_add(t0, t0); t0 = f2_add(x3, t0);
+  t2 = f2_mul(t2, F2_B3);
+  fp2 z3 = f2_add(t1, t2); t1 = f2_sub(t1, t2);
+  y3 = f2_mul(y3, F2_B3);
+  x3 = f2_mul(t4, y3); t2 = f2_mul(t3, t1); x3 = f2_sub(t2, x3);
+  y3 = f2_mul(y3, t0); t1 = f2_mul(t1, z3); y3 = f2_add(t1, y3);
+  t0 = f2_mul(t0, t3); z3 = f2_mul(z3, t4); z3 = f2_add(z3, t0);
+  g2p r = {x3, y3, z3};
+  return r;
+}
+static g2p g2_dbl(g2p a) {                        /* RCB Alg 9, g2.rs:834-863 */
+  fp2 t0 = f2_sqr(a.y);
+  fp2 z3 = f2_dbl(f2_dbl(f2_dbl(t0)));
+  fp2 t1 = f2_mul(a.y, a.z);
+  fp2 t2 = f2_mul(f2_sqr(a.z), F2_B3);
+  fp2 x3 = f2_mul(t2, z3);
+  fp2 y3 = f2_add(t0, t2);
+  z3 = f2_mul(t1, z3);
+  t1 = f2_dbl(t2); t2 = f2_add(t1, t2);
+  t0 = f2_sub(t0, t2);
+  y3 = f2_add(x3, f2_mul(t0, y3));
+  t1 = f2_mul(a.x, a.y);
+  x3 = f2_dbl(f2_mul(t0, t1));
+  g2p r = {x3, y3, z3};
+  return r;
+}
+static g2p g2_neg(g2p a) { a.y = f2_neg(a.y); return a; }
+static g2p g2_mul_limbs(g2p p, const u64 k[4]) {  /* g2.rs:866-886 */
+  g2p acc = g2_identity();
+  for (int i = 255; i >= 0; --i) {
+    acc = g2_dbl(acc);
+    if ((k[i / 64] >> (i % 64)) & 1) acc = g2_add(acc, p);
+  }
+  return acc;
+}
+static g2p g2_mul_u64(g2p p, u64 k) { u64 e[4] = {k, 0, 0, 0}; return g2_mul_limbs(p, e); }
+static g2p g2_psi(g2p a) {                        /* g2.rs:938-954 */
+  g2p r = {f2_mul(f2_conj(a.x), PSI_X), f2_mul(f2_conj(a.y), PSI_Y), f2_conj(a.z)};
+  return r;
+}
+static int g2p_eq(g2p a, g2p b) {                 /* projective equality */
+  int ai = f2_is_zero(a.z), bi = f2_is_zero(b.z);
+  if (ai || bi) return ai && bi;
+  return f2_eq(f2_mul(a.x, b.z), f2_mul(b.x, a.z)) && f2_eq(f2_mul(a.y, b.z), f2_mul(b.y, a.z));
+}
+static g2p g2_clear_cofactor(g2p p) {             /* g2.rs:685-693 */
+  g2p p0 = g2_mul_u64(p, BN_X);
+  g2p p1 = g2_psi(g2_add(g2_dbl(p0), p0));
+  g2p p2 = g2_psi(g2_psi(p0));
+  g2p p3 = g2_psi(g2_psi(g2_psi(p)));
+  return g2_add(g2_add(p0, p1), g2_add(p2, p3));
+}
+static int g2_on_curve_affine(g2a a) {            /* g2.rs:409-414 */
+  if (a.inf) return 1;
+  return f2_eq(f2_sqr(a.y), f2_add(f2_mul(f2_sqr(a.x), a.x), F2_B));
+}
+static int g2_torsion_free_slow(g2a a) {          /* g2.rs:733-736: [r]P == O */
+  return f2_is_zero(g2_mul_limbs(g2_from_affine(a), R_LIMBS).z);
+}
+/* [x+1]P + psi([x]P) + psi^2([x]P) == psi^3([2x]P): same boolean as [r]P == O on E'(Fp2)
+   (checked against the slow test in tests/test_oracle_golden.py, incl. small-order points) */
+static int g2_torsion_free(g2a a) {
+  if (a.inf) return 1;
+  g2p p = g2_from_affine(a);
+  g2p xp = g2_mul_u64(p, BN_X);
+  g2p lhs = g2_add(g2_add(xp, p), g2_add(g2_psi(xp), g2_psi(g2_psi(xp))));
+  g2p rhs = g2_psi(g2_psi(g2_psi(g2_dbl(xp))));
+  return g2p_eq(lhs, rhs);
+}
+static int g2_decode(g2a* r, const uint8_t b[128]) {   /* g2.rs:350-388, order x.c1 x.c0 y.c1 y.c0 */
+  if (!fp_from_be(&r->x.c1, b) || !fp_from_be(&r->x.c0, b + 32)) return 0;
+  if (f2_is_zero(r->x)) { r->y = F2_ONE; r->inf = 1; return 1; }
+  if (!fp_from_be(&r->y.c1, b + 64) || !fp_from_be(&r->y.c0, b + 96)) return 0;
+  r->inf = 0; return 1;
+}
+static void g2_encode(uint8_t b[128], g2a a) {    /* g2.rs:292-300 */
+  if (a.inf) { a.x = F2_ZERO; a.y = F2_ONE; }
+  fp_to_be(b, a.x.c1); fp_to_be(b + 32, a.x.c0); fp_to_be(b + 64, a.y.c1); fp_to_be(b + 96, a.y.c0);
+}
+
+/* ------------------------------------------------------------------ SHA-256 + expand_message_xmd */
+static const uint32_t K256[64] = {
+  0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+  0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+  0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+  0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+  0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+  0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+  0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+typedef struct { uint32_t h[8]; uint8_t buf[64]; size_t fill; u64 total; } sha256_ctx;
+#define ROR(x, n) (((x) >> (n)) | ((x) << (32 - (n))))
+static void sha256_block(uint32_t h[8], const uint8_t* p) {
+  uint32_t w[64];
+  for (int i = 0; i < 16; ++i) w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
+  for (int i = 16; i < 64; ++i) {
+    uint32_t s0 = ROR(w[i - 15], 7) ^ ROR(w[i - 15], 18) ^ (w[i - 15] >> 3);
+    uint32_t s1 = ROR(w[i - 2], 17) ^ ROR(w[i - 2], 19) ^ (w[i - 2] >> 10);
+    w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+  }
+  uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+  for (int i = 0; i < 64; ++i) {
+    uint32_t S1 = ROR(e, 6) ^ ROR(e, 11) ^ ROR(e, 25), ch = (e & f) ^ (~e & g);
+    uint32_t t1 = hh + S1 + ch + K256[i] + w[i];
+    uint32_t S0 = ROR(a, 2) ^ ROR(a, 13) ^ ROR(a, 22), mj = (a & b) ^ (a & c) ^ (b & c);
+    uint32_t t2 = S0 + mj;
+    hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+  }
+  h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+}
+static void sha256_init(sha256_ctx* c) {
+  static const uint32_t iv[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  memcpy(c->h, iv, 32); c->fill = 0; c->total = 0;
+}
+static void sha256_update(sha256_ctx* c, const uint8_t* p, size_t n) {
+  c->total += n;
+  while (n) {
+    size_t k = 64 - c->fill; if (k > n) k = n;
+    memcpy(c->buf + c->fill, p, k); c->fill += k; p += k; n -= k;
+    if (c->fill == 64) { sha256_block(c->h, c->buf); c->fill = 0; }
+  }
+}
+static void sha256_final(sha256_ctx* c, uint8_t out[32]) {
+  u64 bits = c->total * 8;
+  uint8_t pad = 0x80; sha256_update(c, &pad, 1);
+  uint8_t z = 0; while (c->fill != 56) sha256_update(c, &z, 1);
+  uint8_t len[8]; for (int i = 0; i < 8; ++i) len[i] = (uint8_t)(bits >> (8 * (7 - i)));
+  sha256_update(c, len, 8);
+  for (int i = 0; i < 8; ++i) { out[4 * i] = (uint8_t)(c->h[i] >> 24); out[4 * i + 1] = (uint8_t)(c->h[i] >> 16); out[4 * i + 2] = (uint8_t)(c->h[i] >> 8); out[4 * i + 3] = (uint8_t)c->h[i]; }
+}
+void oracle_sha256(const uint8_t* msg, size_t len, uint8_t out[32]) { sha256_ctx c; sha256_init(&c); sha256_update(&c, msg, len); sha256_final(&c, out); }
+
+/* RFC 9380 5.3.1; the reference calls elliptic-curve's ExpandMsgXmd<Sha256> (fp.rs:440, fp2.rs:470) */
+static int expand_message_xmd(uint8_t* out, size_t n, const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len) {
+  uint8_t dst_h[32];
+  if (dst_len > 255) {
+    sha256_ctx c; sha256_init(&c); sha256_update(&c, (const uint8_t*)"H2C-OVERSIZE-DST-", 17); sha256_update(&c, dst, dst_len); sha256_final(&c, dst_h);
+    dst = dst_h; dst_len = 32;
+  }
+  size_t ell = (n + 31) / 32;
+  if (ell > 255 || n > 65535) return -1;
+  uint8_t dlen = (uint8_t)dst_len, b0[32], bi[32], zpad[64], tmp[32];
+  memset(zpad, 0, 64);
+  uint8_t lib[3] = {(uint8_t)(n >> 8), (uint8_t)n, 0};
+  sha256_ctx c; sha256_init(&c);
+  sha256_update(&c, zpad, 64); sha256_update(&c, msg, msg_len); sha256_update(&c, lib, 3);
+  sha256_update(&c, dst, dst_len); sha256_update(&c, &dlen, 1); sha256_final(&c, b0);
+  uint8_t one = 1;
+  sha256_init(&c); sha256_update(&c, b0, 32); sha256_update(&c, &one, 1); sha256_update(&c, dst, dst_len); sha256_update(&c, &dlen, 1); sha256_final(&c, bi);
+  size_t done = 0;
+  for (size_t i = 1; i <= ell; ++i) {
+    size_t k = n - done; if (k > 32) k = 32;
+    memcpy(out + done, bi, k); done += k;
+    if (i == ell) break;
+    for (int j = 0; j < 32; ++j) tmp[j] = b0[j] ^ bi[j];
+    uint8_t idx = (uint8_t)(i + 1);
+    sha256_init(&c); sha256_update(&c, tmp, 32); sha256_update(&c, &idx, 1); sha256_update(&c, dst, dst_len); sha256_update(&c, &dlen, 1); sha256_final(&c, bi);
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ SVDW maps and hash to curve */
+static fp SV1_C1, SV1_C2, SV1_C3, SV1_C4;
+static fp2 SV2_C1, SV2_C2, SV2_C3, SV2_C4;
+
+static g1a svdw_g1(fp u) {                         /* fp.rs:292-370 */
+  fp tv1 = fp_mul(fp_sqr(u), SV1_C1);
+  fp tv2 = fp_add(FP_ONE, tv1);
+  tv1 = fp_sub(FP_ONE, tv1);
+  fp tv3 = fp_inv(fp_mul(tv1, tv2));
+  fp tv4 = fp_mul(fp_mul(fp_mul(u, tv1), tv3), SV1_C3);
+  fp x1 = fp_sub(SV1_C2, tv4);
+  fp gx1 = fp_add(fp_mul(fp_sqr(x1), x1), FP_B);
+  fp x2 = fp_add(SV1_C2, tv4);
+  fp gx2 = fp_add(fp_mul(fp_sqr(x2), x2), FP_B);
+  fp x3 = fp_mul(fp_sqr(tv2), tv3);
+  x3 = fp_add(fp_mul(fp_sqr(x3), SV1_C4), FP_ONE);
+  int e1 = fp_is_square(gx1);
+  fp x = e1 ? x1 : x3;
+  if (fp_is_square(gx2) && !e1) x = x2;
+  fp gx = fp_add(fp_mul(fp_sqr(x), x), FP_B);
+  fp y; (void)fp_sqrt(&y, gx);
+  if (fp_sgn0(u) != fp_sgn0(y)) y = fp_neg(y);
+  g1a r = {x, y, 0};
+  return r;
+}
+static g2a svdw_g2(fp2 u) {                        /* fp2.rs:224-286 */
+  fp2 tv1 = f2_mul(f2_sqr(u), SV2_C1);
+  fp2 tv2 = f2_add(F2_ONE, tv1);
+  tv1 = f2_sub(F2_ONE, tv1);
+  fp2 tv3 = f2_inv(f2_mul(tv1, tv2));
+  fp2 tv4 = f2_mul(f2_mul(f2_mul(u, tv1), tv3), SV2_C3);
+  fp2 x1 = f2_sub(SV2_C2, tv4);
+  fp2 gx1 = f2_add(f2_mul(f2_sqr(x1), x1), F2_B);
+  fp2 x2 = f2_add(SV2_C2, tv4);
+  fp2 gx2 = f2_add(f2_mul(f2_sqr(x2), x2), F2_B);
+  fp2 x3 = f2_mul(f2_sqr(tv2), tv3);
+  x3 = f2_add(f2_mul(f2_sqr(x3), SV2_C4), F2_ONE);
+  int e1 = f2_is_square(gx1);
+  fp2 x = e1 ? x1 : x3;
+  if (f2_is_square(gx2) && !e1) x = x2;
+  fp2 gx = f2_add(f2_mul(f2_sqr(x), x), F2_B);
+  fp2 y; (void)f2_sqrt(&y, gx);
+  if (f2_sgn0(u) != f2_sgn0(y)) y = f2_neg(y);
+  g2a r = {x, y, 0};
+  return r;
+}
+static int hash_to_g1(g1a* out, const uint8_t* msg, size_t len, const uint8_t* dst, size_t dst_len, int ro) {
+  uint8_t okm[96];
+  if (expand_message_xmd(okm, ro ? 96 : 48, msg, len, dst, dst_len)) return -1;
+  if (!ro) { *out = svdw_g1(fp_from_okm(okm)); return 0; }                      /* g1.rs:922-928 */
+  g1a q0 = svdw_g1(fp_from_okm(okm)), q1 = svdw_g1(fp_from_okm(okm + 48));     /* g1.rs:910-919 */
+  *out = g1_to_affine(g1_add(g1_from_affine(q0), g1_from_affine(q1)));
+  return 0;
+}
+static fp2 f2_from_okm(const uint8_t okm[96]) { fp2 r = {fp_from_okm(okm), fp_from_okm(okm + 48)}; return r; }  /* fp2.rs:454-461 */
+static int hash_to_g2(g2a* out, const uint8_t* msg, size_t len, const uint8_t* dst, size_t dst_len, int ro) {
+  uint8_t okm[192];
+  if (expand_message_xmd(okm, ro ? 192 : 96, msg, len, dst, dst_len)) return -1;
+  g2p q;
+  if (!ro) q = g2_from_affine(svdw_g2(f2_from_okm(okm)));                        /* g2.rs:930-936 */
+  else q = g2_add(g2_from_affine(svdw_g2(f2_from_okm(okm))), g2_from_affine(svdw_g2(f2_from_okm(okm + 96))));  /* g2.rs:919-927 */
+  *out = g2_to_affine(g2_clear_cofactor(q));
+  return 0;
+}
+
+/* ------------------------------------------------------------------ pairing */
+typedef struct { fp2 x, y, z; } g2j;      /* Jacobian T of the Miller loop (E17) */
+static int8_t ATE_NAF[72]; static int ATE_NAF_LEN;
+
+static void doubling_step(g2j* r, fp2* c0, fp2* c1, fp2* c2) {     /* pairings.rs:901-930 */
+  fp2 tmp0 = f2_sqr(r->x), tmp1 = f2_sqr(r->y), tmp2 = f2_sqr(tmp1);
+  fp2 tmp3 = f2_sub(f2_sub(f2_sqr(f2_add(tmp1, r->x)), tmp0), tmp2);
+  tmp3 = f2_dbl(tmp3);
+  fp2 tmp4 = f2_add(f2_dbl(tmp0), tmp0);
+  fp2 tmp6 = f2_add(r->x, tmp4);
+  fp2 tmp5 = f2_sqr(tmp4);
+  fp2 zsq = f2_sqr(r->z);
+  r->x = f2_sub(f2_sub(tmp5, tmp3), tmp3);
+  r->z = f2_sub(f2_sub(f2_sqr(f2_add(r->z, r->y)), tmp1), zsq);
+  r->y = f2_mul(f2_sub(tmp3, r->x), tmp4);
+  tmp2 = f2_dbl(f2_dbl(f2_dbl(tmp2)));
+  r->y = f2_sub(r->y, tmp2);
+  tmp3 = f2_neg(f2_dbl(f2_mul(tmp4, zsq)));
+  tmp6 = f2_sub(f2_sub(f2_sqr(tmp6), tmp0), tmp5);
+  tmp1 = f2_dbl(f2_dbl(tmp1));
+  tmp6 = f2_sub(tmp6, tmp1);
+  tmp0 = f2_dbl(f2_mul(r->z, zsq));
+  *c0 = tmp0; *c1 = tmp3; *c2 = tmp6;
+}
+static void addition_step(g2j* r, fp2 qx, fp2 qy, fp2* c0, fp2* c1, fp2* c2) {   /* pairings.rs:932-962 */
+  fp2 zsq = f2_sqr(r->z), ysq = f2_sqr(qy);
+  fp2 t0 = f2_mul(zsq, qx);
+  fp2 t1 = f2_mul(f2_sub(f2_sub(f2_sqr(f2_add(qy, r->z)), ysq), zsq), zsq);
+  fp2 t2 = f2_sub(t0, r->x);
+  fp2 t3 = f2_sqr(t2);
+  fp2 t4 = f2_dbl(f2_dbl(t3));
+  fp2 t5 = f2_mul(t4, t2);
+  fp2 t6 = f2_sub(f2_sub(t1, r->y), r->y);
+  fp2 t9 = f2_mul(t6, qx);
+  fp2 t7 = f2_mul(t4, r->x);
+  r->x = f2_sub(f2_sub(f2_sub(f2_sqr(t6), t5), t7), t7);
+  r->z = f2_sub(f2_sub(f2_sqr(f2_add(r->z, t2)), zsq), t3);
+  fp2 t10 = f2_add(qy, r->z);
+  fp2 t8 = f2_mul(f2_sub(t7, r->x), t6);
+  t0 = f2_dbl(f2_mul(r->y, t5));
+  r->y = f2_sub(t8, t0);
+  t10 = f2_sub(f2_sub(f2_sqr(t10), ysq), f2_sqr(r->z));
+  t9 = f2_sub(f2_dbl(t9), t10);
+  t10 = f2_dbl(r->z);
+  t6 = f2_neg(t6);
+  t1 = f2_dbl(t6);
+  *c0 = t10; *c1 = t1; *c2 = t9;
+}
+/* f * (c0*yP + c1*xP*w + c2*w^3)   (pairings.rs:888-899 with the D-type slots, E7) */
+static fp12 ell(fp12 f, fp2 c0, fp2 c1, fp2 c2, g1a p) {
+  return f12_mul_by_034(f, f2_mul_fp(c0, p.y), f2_mul_fp(c1, p.x), c2);
+}
+/* optimal ate multi-Miller loop: one shared f^2 per NAF digit of 6x+2 (E4), then the two Frobenius
+   lines l_{T,pi(Q)} and l_{T+pi(Q),-pi^2(Q)}.  Pairs with an identity member are skipped
+   (pairings.rs:820-823). */
+static fp12 multi_miller_loop(const g1a* ps, const g2a* qs, size_t n) {
+  fp12 f = F12_ONE;
+  size_t m = 0;
+  g2j* T = (g2j*)malloc(sizeof(g2j) * (n ? n : 1));
+  size_t* idx = (size_t*)malloc(sizeof(size_t) * (n ? n : 1));
+  for (size_t i = 0; i < n; ++i) if (!ps[i].inf && !qs[i].inf) { idx[m] = i; T[m].x = qs[i].x; T[m].y = qs[i].y; T[m].z = F2_ONE; ++m; }
+  fp2 c0, c1, c2;
+  for (int j = ATE_NAF_LEN - 2; j >= 0 && m; --j) {
+    f = f12_sqr(f);
+    for (size_t k = 0; k < m; ++k) { doubling_step(&T[k], &c0, &c1, &c2); f = ell(f, c0, c1, c2, ps[idx[k]]); }
+    if (ATE_NAF[j]) for (size_t k = 0; k < m; ++k) {
+      const g2a* q = &qs[idx[k]];
+      addition_step(&T[k], q->x, ATE_NAF[j] > 0 ? q->y : f2_neg(q->y), &c0, &c1, &c2);
+      f = ell(f, c0, c1, c2, ps[idx[k]]);
+    }
+  }
+  for (size_t k = 0; k < m; ++k) {
+    const g2a* q = &qs[idx[k]];
+    fp2 q1x = f2_mul(f2_conj(q->x), PSI_X), q1y = f2_mul(f2_conj(q->y), PSI_Y);       /* pi(Q) */
+    fp2 q2x = f2_mul(f2_conj(q1x), PSI_X), q2y = f2_neg(f2_mul(f2_conj(q1y), PSI_Y)); /* -pi^2(Q) */
+    addition_step(&T[k], q1x, q1y, &c0, &c1, &c2); f = ell(f, c0, c1, c2, ps[idx[k]]);
+    addition_step(&T[k], q2x, q2y, &c0, &c1, &c2); f = ell(f, c0, c1, c2, ps[idx[k]]);
+  }
+  free(T); free(idx);
+  return f;
+}
+
+/* ------------------------------------------------------------------ Fr */
+typedef struct { u64 l[4]; } fr;
+static fr fr_mul(fr a, fr b) { fr r; mont_mul(r.l, a.l, b.l, &FR); return r; }
+static fr fr_sub(fr a, fr b) { fr r; mod_sub(r.l, a.l, b.l, &FR); return r; }
+static int fr_from_be(fr* r, const uint8_t b[32]) {
+  u64 t[4]; be32_to_limbs(t, b);
+  if (ge256(t, FR.m)) return 0;
+  mont_mul(r->l, t, FR.r2, &FR); return 1;
+}
+static void fr_canon(u64 out[4], fr a) { static const u64 one[4] = {1, 0, 0, 0}; mont_mul(out, a.l, one, &FR); }
+static fr fr_inv(fr a) {
+  fr r; memcpy(r.l, FR.r1, 32);
+  for (int i = 255; i >= 0; --i) { r = fr_mul(r, r); if ((EXP_RM2[i / 64] >> (i % 64)) & 1) r = fr_mul(r, a); }
+  return r;
+}
+static int fr_is_zero(fr a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+/* lambda_i = prod_{j != i} x_j / (x_j - x_i); returns 1 (InvalidScalarBytes) on bad / zero / duplicate ids */
+static int lagrange_at_zero(fr* lam, const uint8_t* ids, size_t t) {
+  fr* x = (fr*)malloc(sizeof(fr) * (t ? t : 1));
+  int rc = 0;
+  for (size_t i = 0; i < t && !rc; ++i) if (!fr_from_be(&x[i], ids + 32 * i) || fr_is_zero(x[i])) rc = 1;
+  for (size_t i = 0; i < t && !rc; ++i) {
+    fr num, den; memcpy(num.l, FR.r1, 32); den = num;
+    for (size_t j = 0; j < t; ++j) if (j != i) {
+      fr d = fr_sub(x[j], x[i]);
+      if (fr_is_zero(d)) { rc = 1; break; }
+      num = fr_mul(num, x[j]); den = fr_mul(den, d);
+    }
+    if (!rc) lam[i] = fr_mul(num, fr_inv(den));
+  }
+  free(x);
+  return rc;
+}
+
+/* ------------------------------------------------------------------ one-time constants */
+static void div_small(u64 q[4], const u64 a[4], u64 d) {
+  u128 rem = 0;
+  for (int i = 3; i >= 0; --i) { u128 cur = (rem << 64) | a[i]; q[i] = (u64)(cur / d); rem = cur % d; }
+}
+static pthread_once_t once = PTHREAD_ONCE_INIT;
+static void init_impl(void) {
+  modctx_init(&FP, P_LIMBS); modctx_init(&FR, R_LIMBS);
+  memset(&FP_ZERO, 0, sizeof FP_ZERO); memcpy(FP_ONE.l, FP.r1, 32);
+  F2_ZERO.c0 = F2_ZERO.c1 = FP_ZERO; F2_ONE.c0 = FP_ONE; F2_ONE.c1 = FP_ZERO;
+  F6_ZERO.c0 = F6_ZERO.c1 = F6_ZERO.c2 = F2_ZERO; F6_ONE = F6_ZERO; F6_ONE.c0 = F2_ONE;
+  F12_ONE.c0 = F6_ONE; F12_ONE.c1 = F6_ZERO;
+  static const u64 one[4] = {1, 0, 0, 0}, two[4] = {2, 0, 0, 0}, three[4] = {3, 0, 0, 0};
+  u64 t[4];
+  sub256(EXP_PM2, P_LIMBS, two);
+  sub256(t, P_LIMBS, one); div_small(EXP_PM1_2, t, 2); div_small(EXP_PM1_6, t, 6);
+  add256(t, P_LIMBS, one); div_small(EXP_PP1_4, t, 4);
+  sub256(t, P_LIMBS, three); div_small(EXP_PM3_4, t, 4);
+  sub256(EXP_RM2, R_LIMBS, two);
+  FP_B = fp_from_u64(3); FP_B3 = fp_from_u64(9);
+  fp2 xi = {fp_from_u64(9), FP_ONE};
+  fp2 three2 = {fp_from_u64(3), FP_ZERO};
+  F2_B = f2_mul(three2, f2_inv(xi));                       /* 3/(9+u), fp2.rs:335-348 */
+  F2_B3 = f2_add(f2_dbl(F2_B), F2_B);
+  /* Frobenius coefficients */
+  fp2 g = f2_pow(xi, EXP_PM1_6);
+  GAMMA[1][0] = F2_ONE;
+  for (int i = 1; i < 6; ++i) GAMMA[1][i] = f2_mul(GAMMA[1][i - 1], g);
+  for (int i = 0; i < 6; ++i) {
+    GAMMA[2][i] = f2_mul(GAMMA[1][i], f2_conj(GAMMA[1][i]));
+    GAMMA[3][i] = f2_mul(GAMMA[1][i], GAMMA[2][i]);
+  }
+  PSI_X = GAMMA[1][2];                                     /* xi^((p-1)/3), g2.rs:939-942 */
+  PSI_Y = GAMMA[1][3];                                     /* xi^((p-1)/2), g2.rs:944-947 */
+  /* G2 generator (fp2.rs:305-333, canonical big-endian values from SURVEY.md App. A) */
+  static const uint8_t g2gen[128] = {
+    0x19,0x8e,0x93,0x93,0x92,0x0d,0x48,0x3a,0x72,0x60,0xbf,0xb7,0x31,0xfb,0x5d,0x25,0xf1,0xaa,0x49,0x33,0x35,0xa9,0xe7,0x12,0x97,0xe4,0x85,0xb7,0xae,0xf3,0x12,0xc2,
+    0x18,0x00,0xde,0xef,0x12,0x1f,0x1e,0x76,0x42,0x6a,0x00,0x66,0x5e,0x5c,0x44,0x79,0x67,0x43,0x22,0xd4,0xf7,0x5e,0xda,0xdd,0x46,0xde,0xbd,0x5c,0xd9,0x92,0xf6,0xed,
+    0x09,0x06,0x89,0xd0,0x58,0x5f,0xf0,0x75,0xec,0x9e,0x99,0xad,0x69,0x0c,0x33,0x95,0xbc,0x4b,0x31,0x33,0x70,0xb3,0x8e,0xf3,0x55,0xac,0xda,0xdc,0xd1,0x22,0x97,0x5b,
+    0x12,0xc8,0x5e,0xa5,0xdb,0x8c,0x6d,0xeb,0x4a,0xab,0x71,0x80,0x8d,0xcb,0x40,0x8f,0xe3,0xd1,0xe7,0x69,0x0c,0x43,0xd3,0x7b,0x4c,0xe6,0xcc,0x01,0x66,0xfa,0x7d,0xaa};
+  g2_decode(&G2_GEN, g2gen);
+  /* SVDW constants (Z = 1): c1 = g(Z), c2 = -Z/2, c3 = sqrt(-g(Z)(3Z^2+4A)) with sgn0 = 0, c4 = -4g(Z)/(3Z^2+4A) */
+  fp inv2 = fp_inv(fp_from_u64(2)), inv3 = fp_inv(fp_from_u64(3));
+  SV1_C1 = fp_from_u64(4);                                 /* g(1) = 1 + 3 */
+  SV1_C2 = fp_neg(inv2);
+  (void)fp_sqrt(&SV1_C3, fp_neg(fp_from_u64(12)));
+  if (fp_sgn0(SV1_C3)) SV1_C3 = fp_neg(SV1_C3);
+  SV1_C4 = fp_neg(fp_mul(fp_from_u64(16), inv3));
+  SV2_C1 = f2_add(F2_ONE, F2_B);
+  SV2_C2.c0 = fp_neg(inv2); SV2_C2.c1 = FP_ZERO;
+  (void)f2_sqrt(&SV2_C3, f2_neg(f2_add(f2_dbl(SV2_C1), SV2_C1)));
+  if (f2_sgn0(SV2_C3)) SV2_C3 = f2_neg(SV2_C3);
+  SV2_C4 = f2_neg(f2_mul_fp(f2_dbl(f2_dbl(SV2_C1)), inv3));
+  /* NAF(6x+2), least significant digit first */
+  u128 s = (u128)6 * BN_X + 2;
+  int n = 0;
+  while (s) {
+    int d = 0;
+    if (s & 1) { d = 2 - (int)(s & 3); if (d > 0) s -= 1; else s += 1; }
+    ATE_NAF[n++] = (int8_t)d; s >>= 1;
+  }
+  ATE_NAF_LEN = n;
+}
+static void init(void) { pthread_once(&once, init_impl); }
+
+/* ================================================================== exported entry points */
+void oracle_g1_generator(uint8_t out[64]) { init(); g1a g = {fp_from_u64(1), fp_from_u64(2), 0}; g1_encode(out, g); }
+void oracle_g2_generator(uint8_t out[128]) { init(); g2_encode(out, G2_GEN); }
+
+int oracle_miller_loop_batch(const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t* out) {
+  init();
+  for (size_t i = 0; i < n; ++i) {
+    g1a p; g2a q;
+    if (!g1_decode(&p, g1 + 64 * i)) return 2;
+    if (!g2_decode(&q, g2 + 128 * i)) return 3;
+    f12_to_bytes(out + 384 * i, multi_miller_loop(&p, &q, 1));
+  }
+  return 0;
+}
+int oracle_pairing_batch(const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t* gt) {   /* pairings.rs:760-802 */
+  init();
+  for (size_t i = 0; i < n; ++i) {
+    g1a p; g2a q;
+    if (!g1_decode(&p, g1 + 64 * i)) return 2;
+    if (!g2_decode(&q, g2 + 128 * i)) return 3;
+    fp12 f = (p.inf || q.inf) ? F12_ONE : final_exponentiation(multi_miller_loop(&p, &q, 1));
+    f12_to_bytes(gt + 384 * i, f);
+  }
+  return 0;
+}
+int oracle_multi_miller_loop(const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t out[384]) {   /* pairings.rs:808-857 */
+  init();
+  g1a* ps = (g1a*)malloc(sizeof(g1a) * (n ? n : 1)); g2a* qs = (g2a*)malloc(sizeof(g2a) * (n ? n : 1));
+  int rc = 0;
+  for (size_t i = 0; i < n && !rc; ++i) {
+    if (!g1_decode(&ps[i], g1 + 64 * i)) rc = 2;
+    else if (!g2_decode(&qs[i], g2 + 128 * i)) rc = 3;
+  }
+  if (!rc) f12_to_bytes(out, multi_miller_loop(ps, qs, n));
+  free(ps); free(qs);
+  return rc;
+}
+int oracle_final_exponentiation(const uint8_t* ml, size_t n, uint8_t* gt) {
+  init();
+  for (size_t i = 0; i < n; ++i) {
+    fp12 f;
+    if (!f12_from_bytes(&f, ml + 384 * i)) return 4;
+    f12_to_bytes(gt + 384 * i, final_exponentiation(f));
+  }
+  return 0;
+}
+static int h2c_batch(const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* out, int g2, int ro) {
+  init();
+  for (size_t i = 0; i < n; ++i) {
+    if (off[i + 1] < off[i]) return -1;
+    if (g2) { g2a q; if (hash_to_g2(&q, msgs + off[i], (size_t)(off[i + 1] - off[i]), dst, dst_len, ro)) return -1; g2_encode(out + 128 * i, q); }
+    else { g1a q; if (hash_to_g1(&q, msgs + off[i], (size_t)(off[i + 1] - off[i]), dst, dst_len, ro)) return -1; g1_encode(out + 64 * i, q); }
+  }
+  return 0;
+}
+int oracle_hash_to_g1_batch(const uint8_t* m, const uint64_t* o, size_t n, const uint8_t* d, size_t dl, uint8_t* out) { return h2c_batch(m, o, n, d, dl, out, 0, 1); }
+int oracle_hash_to_g2_batch(const uint8_t* m, const uint64_t* o, size_t n, const uint8_t* d, size_t dl, uint8_t* out) { return h2c_batch(m, o, n, d, dl, out, 1, 1); }
+int oracle_encode_to_g1_batch(const uint8_t* m, const uint64_t* o, size_t n, const uint8_t* d, size_t dl, uint8_t* out) { return h2c_batch(m, o, n, d, dl, out, 0, 0); }
+int oracle_encode_to_g2_batch(const uint8_t* m, const uint64_t* o, size_t n, const uint8_t* d, size_t dl, uint8_t* out) { return h2c_batch(m, o, n, d, dl, out, 1, 0); }
+int oracle_hash_to_field_fp(const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len, size_t count, uint8_t* out) {
+  init();
+  if (count > 8) return -1;
+  uint8_t okm[48 * 8];
+  if (expand_message_xmd(okm, 48 * count, msg, msg_len, dst, dst_len)) return -1;
+  for (size_t i = 0; i < count; ++i) fp_to_be(out + 32 * i, fp_from_okm(okm + 48 * i));
+  return 0;
+}
+static void set_bit(uint8_t* bm, size_t i, int v) { if (v) bm[i >> 3] |= (uint8_t)(1u << (i & 7)); else bm[i >> 3] &= (uint8_t)~(1u << (i & 7)); }
+int oracle_g1_check_batch(const uint8_t* g1, size_t n, uint8_t* bm) {
+  init();
+  for (size_t i = 0; i < n; ++i) { g1a p; set_bit(bm, i, g1_decode(&p, g1 + 64 * i) && g1_on_curve_affine(p)); }
+  return 0;
+}
+int oracle_g2_check_batch(const uint8_t* g2, size_t n, uint8_t* bm) {
+  init();
+  for (size_t i = 0; i < n; ++i) { g2a q; set_bit(bm, i, g2_decode(&q, g2 + 128 * i) && g2_on_curve_affine(q) && g2_torsion_free(q)); }
+  return 0;
+}
+int oracle_g2_check_batch_slow(const uint8_t* g2, size_t n, uint8_t* bm) {
+  init();
+  for (size_t i = 0; i < n; ++i) { g2a q; set_bit(bm, i, g2_decode(&q, g2 + 128 * i) && g2_on_curve_affine(q) && g2_torsion_free_slow(q)); }
+  return 0;
+}
+/* CoreVerify, min-sig: sig in G1 on curve and != O; pk in G2 on curve, != O, torsion free;
+   e(sig, -G2gen) * e(H(msg), pk) == 1 */
+static int verify_one(const uint8_t pk_b[128], const uint8_t* msg, size_t len, const uint8_t sig_b[64], const uint8_t* dst, size_t dst_len) {
+  g1a sig, h; g2a pk;
+  if (!g1_decode(&sig, sig_b) || sig.inf || !g1_on_curve_affine(sig)) return 0;
+  if (!g2_decode(&pk, pk_b) || pk.inf || !g2_on_curve_affine(pk) || !g2_torsion_free(pk)) return 0;
+  if (hash_to_g1(&h, msg, len, dst, dst_len, 1)) return 0;
+  g1a ps[2] = {sig, h};
+  g2a qs[2] = {G2_GEN, pk};
+  qs[0].y = f2_neg(qs[0].y);
+  return f12_eq(final_exponentiation(multi_miller_loop(ps, qs, 2)), F12_ONE);
+}
+int oracle_verify_batch(const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, size_t n,
+                        const uint8_t* dst, size_t dst_len, uint8_t* bm) {
+  init();
+  for (size_t i = 0; i < n; ++i) {
+    if (off[i + 1] < off[i]) return -1;
+    set_bit(bm, i, verify_one(pks + 128 * i, msgs + off[i], (size_t)(off[i + 1] - off[i]), sigs + 64 * i, dst, dst_len));
+  }
+  return 0;
+}
+typedef struct { const uint8_t *pks, *msgs, *sigs, *dst; const uint64_t* off; size_t lo, hi, dst_len; uint8_t* res; } vjob;
+static void* vworker(void* a) {
+  vjob* j = (vjob*)a;
+  for (size_t i = j->lo; i < j->hi; ++i)
+    j->res[i] = (uint8_t)verify_one(j->pks + 128 * i, j->msgs + j->off[i], (size_t)(j->off[i + 1] - j->off[i]), j->sigs + 64 * i, j->dst, j->dst_len);
+  return NULL;
+}
+int oracle_verify_batch_mt(const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, size_t n,
+                           const uint8_t* dst, size_t dst_len, uint8_t* bm, int nthreads) {
+  init();
+  if (nthreads < 1) nthreads = 1;
+  if (nthreads > 256) nthreads = 256;
+  for (size_t i = 0; i < n; ++i) if (off[i + 1] < off[i]) return -1;
+  uint8_t* res = (uint8_t*)calloc(n ? n : 1, 1);
+  pthread_t th[256]; vjob jobs[256];
+  for (int t = 0; t < nthreads; ++t) {
+    vjob j = {pks, msgs, sigs, dst, off, n * (size_t)t / (size_t)nthreads, n * (size_t)(t + 1) / (size_t)nthreads, dst_len, res};
+    jobs[t] = j; pthread_create(&th[t], NULL, vworker, &jobs[t]);
+  }
+  for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
+  for (size_t i = 0; i < n; ++i) set_bit(bm, i, res[i]);
+  free(res);
+  return 0;
+}
+/* CoreAggregateVerify: prod e(H(m_i), pk_i) * e(sig, -G2gen) == 1; n == 0 -> invalid */
+int oracle_aggregate_verify(const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t agg_sig[64],
+                            const uint8_t* dst, size_t dst_len, int* valid) {
+  init();
+  *valid = 0;
+  if (n == 0) return 0;
+  g1a sig;
+  if (!g1_decode(&sig, agg_sig) || sig.inf || !g1_on_curve_affine(sig)) return 0;
+  g1a* ps = (g1a*)malloc(sizeof(g1a) * (n + 1)); g2a* qs = (g2a*)malloc(sizeof(g2a) * (n + 1));
+  int ok = 1, rc = 0;
+  for (size_t i = 0; i < n && ok; ++i) {
+    if (off[i + 1] < off[i]) { rc = -1; ok = 0; break; }
+    if (!g2_decode(&qs[i], pks + 128 * i) || qs[i].inf || !g2_on_curve_affine(qs[i]) || !g2_torsion_free(qs[i])) ok = 0;
+    else if (hash_to_g1(&ps[i], msgs + off[i], (size_t)(off[i + 1] - off[i]), dst, dst_len, 1)) ok = 0;
+  }
+  if (ok) {
+    ps[n] = sig; qs[n] = G2_GEN; qs[n].y = f2_neg(qs[n].y);
+    *valid = f12_eq(final_exponentiation(multi_miller_loop(ps, qs, n + 1)), F12_ONE);
+  }
+  free(ps); free(qs);
+  return rc;
+}
+int oracle_aggregate_sigs(const uint8_t* sigs, size_t n, uint8_t out[64]) {     /* impl Sum, g1.rs:561-565 */
+  init();
+  g1p acc = g1_identity();
+  for (size_t i = 0; i < n; ++i) { g1a s; if (!g1_decode(&s, sigs + 64 * i)) return 2; acc = g1_add(acc, g1_from_affine(s)); }
+  g1_encode(out, g1_to_affine(acc));
+  return 0;
+}
+int oracle_fr_lagrange_at_zero(const uint8_t* ids, size_t t, uint8_t* out) {
+  init();
+  fr* lam = (fr*)malloc(sizeof(fr) * (t ? t : 1));
+  int rc = lagrange_at_zero(lam, ids, t);
+  if (!rc) for (size_t i = 0; i < t; ++i) { u64 c[4]; fr_canon(c, lam[i]); limbs_to_be32(out + 32 * i, c); }
+  free(lam);
+  return rc;
+}
+int oracle_threshold_combine(const uint8_t* ids, const uint8_t* sigs, size_t t, uint8_t out[64]) {
+  init();
+  fr* lam = (fr*)malloc(sizeof(fr) * (t ? t : 1));
+  int rc = lagrange_at_zero(lam, ids, t);
+  g1p acc = g1_identity();
+  for (size_t i = 0; i < t && !rc; ++i) {
+    g1a s; u64 k[4];
+    if (!g1_decode(&s, sigs + 64 * i)) { rc = 2; break; }
+    fr_canon(k, lam[i]);
+    acc = g1_add(acc, g1_mul_limbs(g1_from_affine(s), k));
+  }
+  if (!rc) g1_encode(out, g1_to_affine(acc));
+  free(lam);
+  return rc;
+}
+int oracle_g1_mul(const uint8_t g1[64], const uint8_t k_be[32], uint8_t out[64]) {
+  init();
+  g1a p; u64 k[4];
+  if (!g1_decode(&p, g1)) return 2;
+  be32_to_limbs(k, k_be);
+  g1_encode(out, g1_to_affine(g1_mul_limbs(g1_from_affine(p), k)));
+  return 0;
+}
+int oracle_g2_mul(const uint8_t g2[128], const uint8_t k_be[32], uint8_t out[128]) {
+  init();
+  g2a q; u64 k[4];
+  if (!g2_decode(&q, g2)) return 3;
+  be32_to_limbs(k, k_be);
+  g2_encode(out, g2_to_affine(g2_mul_limbs(g2_from_affine(q), k)));
+  return 0;
+}
+int oracle_g1_add(const uint8_t a[64], const uint8_t b[64], uint8_t out[64]) {
+  init();
+  g1a p, q;
+  if (!g1_decode(&p, a) || !g1_decode(&q, b)) return 2;
+  g1_encode(out, g1_to_affine(g1_add(g1_from_affine(p), g1_from_affine(q))));
+  return 0;
+}
+int oracle_g2_add(const uint8_t a[128], const uint8_t b[128], uint8_t out[128]) {
+  init();
+  g2a p, q;
+  if (!g2_decode(&p, a) || !g2_decode(&q, b)) return 3;
+  g2_encode(out, g2_to_affine(g2_add(g2_from_affine(p), g2_from_affine(q))));
+  return 0;
+}
+int oracle_sk_to_pk(const uint8_t sk_be[32], uint8_t pk[128]) {
+  init();
+  u64 k[4]; be32_to_limbs(k, sk_be);
+  if (ge256(k, FR.m)) return 1;
+  g2_encode(pk, g2_to_affine(g2_mul_limbs(g2_from_affine(G2_GEN), k)));
+  return 0;
+}
+int oracle_sign(const uint8_t sk_be[32], const uint8_t* msg, size_t msg_len, const uint8_t* dst, size_t dst_len, uint8_t sig[64]) {
+  init();
+  u64 k[4]; be32_to_limbs(k, sk_be);
+  if (ge256(k, FR.m)) return 1;
+  g1a h;
+  if (hash_to_g1(&h, msg, msg_len, dst, dst_len, 1)) return -1;
+  g1_encode(sig, g1_to_affine(g1_mul_limbs(g1_from_affine(h), k)));
+  return 0;
+}
+int oracle_gt_mul(const uint8_t a[384], const uint8_t b[384], uint8_t out[384]) {
+  init();
+  fp12 x, y;
+  if (!f12_from_bytes(&x, a) || !f12_from_bytes(&y, b)) return 4;
+  f12_to_bytes(out, f12_mul(x, y));
+  return 0;
+}
+int oracle_gt_pow(const uint8_t gt[384], const uint8_t k_be[32], uint8_t out[384]) {   /* Gt::mul_by_scalar, pairings.rs:585-600 */
+  init();
+  fp12 x, acc = F12_ONE; u64 k[4];
+  if (!f12_from_bytes(&x, gt)) return 4;
+  be32_to_limbs(k, k_be);
+  for (int i = 255; i >= 0; --i) { acc = f12_sqr(acc); if ((k[i / 64] >> (i % 64)) & 1) acc = f12_mul(acc, x); }
+  f12_to_bytes(out, acc);
+  return 0;
+}
