@@ -1,0 +1,306 @@
+// curve.h -- G1 (y^2 = x^3 + 3 over Fp) and G2 (y^2 = x^3 + 3/(9+u) over Fp2): codecs, on-curve and
+// subgroup checks, complete projective group law, SVDW map and hash-to-curve glue.
+//
+// Reference operators replaced:
+//   G1Affine::{from,to}_uncompressed g1.rs:297-302,:339-360 ; is_on_curve :383-391
+//   G1Projective::{addition,double,multiply} g1.rs:704-841 ; hash/encode :910-928
+//   G2Affine::{from,to}_uncompressed g2.rs:292-300,:350-388 ; is_on_curve :409-414
+//   G2Projective::{addition,double,multiply,psi,clear_cofactor,is_torsion_free} g2.rs:685-954
+//   MapToCurve for Fp / Fp2 (SVDW) fp.rs:284-371, fp2.rs:221-287
+// The group law is the same complete (Renes-Costello-Batina 2015/1060 Alg 7/9) formula set the
+// reference uses, so every lane runs an identical instruction stream with no special cases.  The
+// cross terms are formed subtractively (X1Y2 + X2Y1 = X1X2 + Y1Y2 - (X1-Y1)(X2-Y2)) to stay inside the
+// lazy-limb intervals of fp29.h.
+#pragma once
+#include "tower.h"
+
+namespace bn {
+
+// ------------------------------------------------------------------ field-generic helpers
+BN_INL Fp f_add(const Fp& a, const Fp& b) { return fp_add(a, b); }
+BN_INL Fp f_sub(const Fp& a, const Fp& b) { return fp_sub(a, b); }
+BN_INL Fp f_mul(const Fp& a, const Fp& b) { return fp_mul(a, b); }
+BN_INL Fp f_sqr(const Fp& a) { return fp_sqr(a); }
+BN_INL Fp f_norm(const Fp& a) { return fp_norm(a); }
+BN_INL Fp f_neg(const Fp& a) { return fp_neg(a); }
+BN_INL bool f_is_zero(const Fp& a) { return fp_is_zero(a); }
+BN_INL Fp f_select(bool c, const Fp& a, const Fp& b) { return fp_select(c, a, b); }
+BN_INL Fp f_mul_b3(const Fp& a) { return fp_lc2<9, 0>(a, a); }                     // 3b = 9 (fp.rs:414)
+template <int K1, int K2> BN_INL Fp f_lc2(const Fp& a, const Fp& b) { return fp_lc2<K1, K2>(a, b); }
+template <int K1, int K2, int K3> BN_INL Fp f_lc3(const Fp& a, const Fp& b, const Fp& c) { return fp_lc3<K1, K2, K3>(a, b, c); }
+BN_INL void f_set_zero(Fp& a) { a = fp_zero(); }
+BN_INL void f_set_one(Fp& a) { a = fp_one(); }
+
+BN_INL Fp2 f_add(const Fp2& a, const Fp2& b) { return fp2_add(a, b); }
+BN_INL Fp2 f_sub(const Fp2& a, const Fp2& b) { return fp2_sub(a, b); }
+BN_INL Fp2 f_mul(const Fp2& a, const Fp2& b) { return fp2_mul(a, b); }
+BN_INL Fp2 f_sqr(const Fp2& a) { return fp2_sqr(a); }
+BN_INL Fp2 f_norm(const Fp2& a) { return fp2_norm(a); }
+BN_INL Fp2 f_neg(const Fp2& a) { return fp2_neg(a); }
+BN_INL bool f_is_zero(const Fp2& a) { return fp2_is_zero(a); }
+BN_INL Fp2 f_select(bool c, const Fp2& a, const Fp2& b) { return fp2_select(c, a, b); }
+BN_INL Fp2 f_mul_b3(const Fp2& a) { return fp2_mul(a, fp2_const(bnc::B2_3)); }      // fp2.rs:411-413
+template <int K1, int K2> BN_INL Fp2 f_lc2(const Fp2& a, const Fp2& b) { return {fp_lc2<K1, K2>(a.c0, b.c0), fp_lc2<K1, K2>(a.c1, b.c1)}; }
+template <int K1, int K2, int K3> BN_INL Fp2 f_lc3(const Fp2& a, const Fp2& b, const Fp2& c) {
+  return {fp_lc3<K1, K2, K3>(a.c0, b.c0, c.c0), fp_lc3<K1, K2, K3>(a.c1, b.c1, c.c1)};
+}
+BN_INL void f_set_zero(Fp2& a) { a = fp2_zero(); }
+BN_INL void f_set_one(Fp2& a) { a = fp2_one(); }
+
+// ------------------------------------------------------------------ points
+template <class F> struct Aff { F x, y; bool inf; };
+template <class F> struct Proj { F x, y, z; };        // homogeneous; identity = (0, 1, 0)
+typedef Aff<Fp> G1A;
+typedef Aff<Fp2> G2A;
+typedef Proj<Fp> G1P;
+typedef Proj<Fp2> G2P;
+
+template <class F> BN_INL Proj<F> proj_identity() { Proj<F> r; f_set_zero(r.x); f_set_one(r.y); f_set_zero(r.z); return r; }
+template <class F> BN_INL Proj<F> proj_from_affine(const Aff<F>& a) {
+  Proj<F> id = proj_identity<F>(), r;
+  F one; f_set_one(one);
+  r.x = f_select(a.inf, id.x, a.x); r.y = f_select(a.inf, id.y, a.y); r.z = f_select(a.inf, id.z, one);
+  return r;
+}
+// complete addition, RCB Alg 7 with a = 0 (g1.rs:744-786, g2.rs:789-831); inputs/outputs normalised
+template <class F> BN_HD inline Proj<F> proj_add(const Proj<F>& a, const Proj<F>& b) {
+  BN_CTX;
+  F t0 = f_mul(a.x, b.x), t1 = f_mul(a.y, b.y), t2 = f_mul(a.z, b.z);
+  F m3 = f_mul(f_sub(a.x, a.y), f_sub(b.x, b.y));
+  F m4 = f_mul(f_sub(a.y, a.z), f_sub(b.y, b.z));
+  F m5 = f_mul(f_sub(a.x, a.z), f_sub(b.x, b.z));
+  F t3 = f_lc3<1, 1, -1>(t0, t1, m3);              // X1Y2 + X2Y1
+  F t4 = f_lc3<1, 1, -1>(t1, t2, m4);              // Y1Z2 + Y2Z1
+  F y3 = f_lc3<1, 1, -1>(t0, t2, m5);              // X1Z2 + X2Z1
+  F t0_3 = f_lc2<3, 0>(t0, t0);                    // 3 X1X2
+  F bt2 = f_mul_b3(t2);
+  F z3 = f_norm(f_add(t1, bt2));
+  F t1m = f_norm(f_sub(t1, bt2));
+  F by3 = f_mul_b3(y3);
+  F x3 = f_norm(f_sub(f_mul(t3, t1m), f_mul(t4, by3)));
+  F yy = f_norm(f_add(f_mul(t1m, z3), f_mul(by3, t0_3)));
+  F zz = f_norm(f_add(f_mul(z3, t4), f_mul(t0_3, t3)));
+  return {x3, yy, zz};
+}
+// doubling, RCB Alg 9 (g1.rs:788-818, g2.rs:834-863)
+template <class F> BN_HD inline Proj<F> proj_dbl(const Proj<F>& a) {
+  BN_CTX;
+  F t0 = f_sqr(a.y);
+  F z8 = f_lc2<8, 0>(t0, t0);
+  F t1 = f_mul(a.y, a.z);
+  F t2 = f_mul_b3(f_sqr(a.z));
+  F x3 = f_mul(t2, z8);
+  F y3 = f_norm(f_add(t0, t2));
+  F z3 = f_mul(t1, z8);
+  F t0m = f_lc2<1, -3>(t0, t2);                    // t0 - 3 t2
+  F yy = f_norm(f_add(x3, f_mul(t0m, y3)));
+  F xy = f_mul(a.x, a.y);
+  F xx = f_lc2<2, 0>(f_mul(t0m, xy), t0);
+  return {xx, yy, z3};
+}
+template <class F> BN_INL Proj<F> proj_neg(const Proj<F>& a) { return {a.x, f_norm(f_neg(a.y)), a.z}; }
+template <class F> BN_INL Proj<F> proj_select(bool c, const Proj<F>& a, const Proj<F>& b) {
+  return {f_select(c, a.x, b.x), f_select(c, a.y, b.y), f_select(c, a.z, b.z)};
+}
+// k * P for a 64-bit public scalar (uniform bits): left-to-right double and add
+template <class F> BN_HD inline Proj<F> proj_mul_u64(const Proj<F>& p, uint64_t k) {
+  BN_CTX;
+  Proj<F> acc = proj_identity<F>();
+  for (int i = 63; i >= 0; --i) {
+    acc = proj_dbl(acc);
+    if ((k >> i) & 1) acc = proj_add(acc, p);
+  }
+  return acc;
+}
+// k * P for a per-lane 256-bit scalar (4 x u64, little endian): branch-free select per bit
+template <class F> BN_HD inline Proj<F> proj_mul_256(const Proj<F>& p, const uint64_t* k) {
+  BN_CTX;
+  Proj<F> acc = proj_identity<F>();
+  for (int i = 255; i >= 0; --i) {
+    acc = proj_dbl(acc);
+    Proj<F> s = proj_add(acc, p);
+    acc = proj_select((k[i >> 6] >> (i & 63)) & 1, s, acc);
+  }
+  return acc;
+}
+template <class F> BN_INL bool proj_eq(const Proj<F>& a, const Proj<F>& b) {
+  bool ai = f_is_zero(a.z), bi = f_is_zero(b.z);
+  bool e = f_is_zero(f_sub(f_mul(a.x, b.z), f_mul(b.x, a.z))) & f_is_zero(f_sub(f_mul(a.y, b.z), f_mul(b.y, a.z)));
+  return (ai | bi) ? (ai & bi) : e;
+}
+
+// ------------------------------------------------------------------ G1 codec / checks
+// strict decode: canonical coordinates, x == 0 -> identity (g1.rs:352-353); no on-curve check (E10)
+BN_INL G1A g1_decode(const uint8_t* b, bool& ok) {
+  bool okx, oky;
+  G1A r;
+  r.x = fp_from_be(b, okx);
+  r.y = fp_from_be(b + 32, oky);
+  r.inf = okx & fp_is_zero(r.x);
+  ok = okx & (r.inf | oky);
+  return r;
+}
+BN_INL void g1_encode(uint8_t* b, const G1A& a) {               // identity = (0, 1) (g1.rs:265-271)
+  fp_to_be(b, fp_select(a.inf, fp_zero(), a.x));
+  fp_to_be(b + 32, fp_select(a.inf, fp_one(), a.y));
+}
+BN_INL bool g1_on_curve(const G1A& a) {                          // g1.rs:383-391
+  Fp rhs = fp_add(fp_mul(fp_sqr(a.x), a.x), fp_const(bnc::THREE));
+  return a.inf | fp_is_zero(fp_sub(fp_sqr(a.y), rhs));
+}
+BN_HD inline G1A g1_to_affine(const G1P& p) {
+  BN_CTX;
+  G1A r;
+  r.inf = fp_is_zero(p.z);
+  Fp zi = fp_inv(p.z);
+  r.x = fp_mul(p.x, zi); r.y = fp_mul(p.y, zi);
+  return r;
+}
+
+// ------------------------------------------------------------------ G2 codec / checks
+BN_INL G2A g2_decode(const uint8_t* b, bool& ok) {              // x.c1 | x.c0 | y.c1 | y.c0 (g2.rs:350-388)
+  bool o0, o1, o2, o3;
+  G2A r;
+  r.x.c1 = fp_from_be(b, o0); r.x.c0 = fp_from_be(b + 32, o1);
+  r.y.c1 = fp_from_be(b + 64, o2); r.y.c0 = fp_from_be(b + 96, o3);
+  r.inf = o0 & o1 & fp2_is_zero(r.x);
+  ok = o0 & o1 & (r.inf | (o2 & o3));
+  return r;
+}
+BN_INL void g2_encode(uint8_t* b, const G2A& a) {               // g2.rs:292-300
+  Fp2 x = fp2_select(a.inf, fp2_zero(), a.x), y = fp2_select(a.inf, fp2_one(), a.y);
+  fp_to_be(b, x.c1); fp_to_be(b + 32, x.c0); fp_to_be(b + 64, y.c1); fp_to_be(b + 96, y.c0);
+}
+BN_INL bool g2_on_curve(const G2A& a) {                          // g2.rs:409-414
+  Fp2 rhs = fp2_add(fp2_mul(fp2_sqr(a.x), a.x), fp2_const(bnc::B2));
+  return a.inf | fp2_is_zero(fp2_sub(fp2_sqr(a.y), rhs));
+}
+BN_HD inline G2A g2_to_affine(const G2P& p) {
+  BN_CTX;
+  G2A r;
+  r.inf = fp2_is_zero(p.z);
+  Fp2 zi = fp2_inv(p.z);
+  r.x = fp2_mul(p.x, zi); r.y = fp2_mul(p.y, zi);
+  return r;
+}
+BN_INL G2P g2_psi(const G2P& a) {                                // g2.rs:938-954
+  return {fp2_mul(fp2_norm(fp2_conj(a.x)), fp2_const(bnc::GAMMA1[1])),
+          fp2_mul(fp2_norm(fp2_conj(a.y)), fp2_const(bnc::GAMMA1[2])),
+          fp2_norm(fp2_conj(a.z))};
+}
+// Subgroup membership.  The reference computes [r]P (254 doublings + additions, g2.rs:733-736); the
+// same boolean is obtained from one 63-bit multiplication and the untwist-Frobenius-twist map:
+//   [x+1]P + psi([x]P) + psi^2([x]P) == psi^3([2x]P)
+// (equivalence incl. small-order points is tested against [r]P in tests/test_oracle_golden.py).
+BN_HD inline bool g2_torsion_free(const G2A& a) {
+  BN_CTX;
+  G2P p = proj_from_affine(a);
+  G2P xp = proj_mul_u64(p, bnc::BN_X);
+  G2P p1 = g2_psi(xp);
+  G2P lhs = proj_add(proj_add(xp, p), proj_add(p1, g2_psi(p1)));
+  G2P rhs = g2_psi(g2_psi(g2_psi(proj_dbl(xp))));
+  return a.inf | proj_eq(lhs, rhs);
+}
+BN_HD inline G2P g2_clear_cofactor(const G2P& p) {               // g2.rs:685-693
+  G2P p0 = proj_mul_u64(p, bnc::BN_X);
+  G2P p1 = g2_psi(proj_add(proj_dbl(p0), p0));
+  G2P p2 = g2_psi(g2_psi(p0));
+  G2P p3 = g2_psi(g2_psi(g2_psi(p)));
+  return proj_add(proj_add(p0, p1), proj_add(p2, p3));
+}
+
+// ------------------------------------------------------------------ SVDW maps
+// Straight-line Shallue-van de Woestijne (RFC 9380 F.1), Z = 1, following fp.rs:292-370.  The two
+// is_square tests and the final sqrt of the reference (three Euler/sqrt exponentiations) are each
+// done as ONE a^((p+1)/4) exponentiation whose square is compared with a (fp_sqrt_cand).
+BN_HD inline G1A svdw_g1(const Fp& u_in) {
+  BN_CTX;
+  Fp u = fp_norm(u_in);
+  Fp c2 = fp_const(bnc::SVDW1_C2), c3 = fp_const(bnc::SVDW1_C3), c4 = fp_const(bnc::SVDW1_C4), one = fp_one(), b = fp_const(bnc::THREE);
+  Fp u2 = fp_sqr(u);
+  Fp tv1 = fp_lc2<4, 0>(u2, u2);                                 // c1 = g(Z) = 4
+  Fp tv2 = fp_norm(fp_add(one, tv1));
+  tv1 = fp_norm(fp_sub(one, tv1));
+  Fp tv3 = fp_inv(fp_mul(tv1, tv2));                             // inv0
+  Fp tv4 = fp_mul(fp_mul(fp_mul(u, tv1), tv3), c3);
+  Fp x1 = fp_norm(fp_sub(c2, tv4));
+  Fp gx1 = fp_norm(fp_add(fp_mul(fp_sqr(x1), x1), b));
+  Fp x2 = fp_norm(fp_add(c2, tv4));
+  Fp gx2 = fp_norm(fp_add(fp_mul(fp_sqr(x2), x2), b));
+  Fp x3 = fp_mul(fp_sqr(tv2), tv3);
+  x3 = fp_norm(fp_add(fp_mul(fp_sqr(x3), c4), one));
+  Fp gx3 = fp_norm(fp_add(fp_mul(fp_sqr(x3), x3), b));
+  bool e1, e2, e3;
+  Fp y1 = fp_sqrt_cand(gx1, e1), y2 = fp_sqrt_cand(gx2, e2), y3 = fp_sqrt_cand(gx3, e3);
+  G1A r;
+  r.x = fp_select(e1, x1, fp_select(e2, x2, x3));
+  Fp y = fp_select(e1, y1, fp_select(e2, y2, y3));
+  bool flip = fp_sgn0(u) != fp_sgn0(y);
+  r.y = fp_select(flip, fp_norm(fp_neg(y)), y);
+  r.inf = false;
+  return r;
+}
+// hash_to_curve for G1 (g1.rs:910-919): map two field elements, add, no cofactor
+BN_HD inline G1A hash_to_g1_from_fields(const Fp& u0, const Fp& u1) {
+  BN_CTX;
+  G1A q0 = svdw_g1(u0), q1 = svdw_g1(u1);
+  return g1_to_affine(proj_add(proj_from_affine(q0), proj_from_affine(q1)));
+}
+
+// Fp2 helpers for the G2 map
+BN_HD inline Fp2 fp2_pow(const Fp2& a, const uint64_t (&e)[4]) {
+  BN_CTX;
+  Fp2 base = fp2_norm(a), r = fp2_one();
+  for (int i = 255; i >= 0; --i) {
+    r = fp2_sqr(r);
+    Fp2 m = fp2_mul(r, base);
+    r = fp2_select((e[i >> 6] >> (i & 63)) & 1, m, r);
+  }
+  return r;
+}
+BN_HD inline bool fp2_is_square(const Fp2& a) {                  // fp2.rs:441-452: norm is a square in Fp
+  Fp2 n = fp2_norm(a);
+  bool e;
+  (void)fp_sqrt_cand(fp_dot2(n.c0, n.c0, n.c1, n.c1), e);
+  return e;
+}
+// Algorithm 9 of eprint 2012/685 (fp2.rs:172-218); returns a root when a is a square
+BN_HD inline Fp2 fp2_sqrt(const Fp2& a_in) {
+  BN_CTX;
+  Fp2 a = fp2_norm(a_in);
+  Fp2 a1 = fp2_pow(a, bnc::EXP_PM3_4);
+  Fp2 alpha = fp2_mul(fp2_sqr(a1), a);
+  Fp2 x0 = fp2_mul(a1, a);
+  bool neg_one = fp2_is_zero(fp2_add(alpha, fp2_one()));
+  Fp2 alt = {fp_norm(fp_neg(x0.c1)), x0.c0};
+  Fp2 b = fp2_pow(fp2_norm(fp2_add(alpha, fp2_one())), bnc::EXP_PM1_2);
+  Fp2 r = fp2_mul(b, x0);
+  return fp2_select(neg_one, alt, r);
+}
+BN_HD inline G2A svdw_g2(const Fp2& u_in) {                      // fp2.rs:224-286
+  Fp2 u = fp2_norm(u_in);
+  Fp2 c1 = fp2_const(bnc::SVDW2_C1), c3 = fp2_const(bnc::SVDW2_C3), c4 = fp2_const(bnc::SVDW2_C4), one = fp2_one(), b = fp2_const(bnc::B2);
+  Fp2 c2 = {fp_const(bnc::SVDW1_C2), fp_zero()};
+  Fp2 tv1 = fp2_mul(fp2_sqr(u), c1);
+  Fp2 tv2 = fp2_norm(fp2_add(one, tv1));
+  tv1 = fp2_norm(fp2_sub(one, tv1));
+  Fp2 tv3 = fp2_inv(fp2_mul(tv1, tv2));
+  Fp2 tv4 = fp2_mul(fp2_mul(fp2_mul(u, tv1), tv3), c3);
+  Fp2 x1 = fp2_norm(fp2_sub(c2, tv4));
+  Fp2 gx1 = fp2_norm(fp2_add(fp2_mul(fp2_sqr(x1), x1), b));
+  Fp2 x2 = fp2_norm(fp2_add(c2, tv4));
+  Fp2 gx2 = fp2_norm(fp2_add(fp2_mul(fp2_sqr(x2), x2), b));
+  Fp2 x3 = fp2_mul(fp2_sqr(tv2), tv3);
+  x3 = fp2_norm(fp2_add(fp2_mul(fp2_sqr(x3), c4), one));
+  bool e1 = fp2_is_square(gx1), e2 = fp2_is_square(gx2);
+  G2A r;
+  r.x = fp2_select(e1, x1, fp2_select(e2, x2, x3));
+  Fp2 gx = fp2_norm(fp2_add(fp2_mul(fp2_sqr(r.x), r.x), b));
+  Fp2 y = fp2_sqrt(gx);
+  bool flip = fp2_sgn0(u) != fp2_sgn0(y);
+  r.y = fp2_select(flip, fp2_norm(fp2_neg(y)), y);
+  r.inf = false;
+  return r;
+}
+
+}  // namespace bn

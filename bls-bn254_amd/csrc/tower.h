@@ -1,0 +1,216 @@
+// tower.h -- Fp2 = Fp[u]/(u^2+1), Fp6 = Fp2[v]/(v^3 - xi), Fp12 = Fp6[w]/(w^2 - v), xi = 9+u,
+// on the lazy radix-2^29 base field of fp29.h.
+//
+// Reference operators replaced (values identical, formulas chosen for gfx950):
+//   Fp2  mul/square/invert/conjugate      fp2.rs:377-437, :161-166
+//   Fp6  multiply/mul_by_01/mul_by_1/invert  fp6.rs:123-152, :225-287   (xi fixed to 9+u, E1)
+//   Fp12 multiply/square/conjugate/invert/frobenius, sparse multiply  fp12.rs:120-219 (E3, E7)
+//   fp4_square / cyclotomic_square        pairings.rs:52-115
+//
+// Design notes:
+//  * Fp2 multiplication is "schoolbook-lazy": c0 = a0*b0 - a1*b1 and c1 = a0*b1 + a1*b0 are each ONE
+//    double product accumulated in the 64-bit columns and reduced once (fp_dot2): 4*81 MADs + 2
+//    reductions = 572 VALU ops, cheaper than Karatsuba (3 full multiplies + 5 additions = 660)
+//    because on gfx950 a MAD costs about the same as an add.
+//  * Karatsuba at the Fp6/Fp12 level is SUBTRACTIVE ((a0-a1)(b1-b0) + a0b0 + a1b1): differences of
+//    normalised non-negative limbs stay within one limb width, so the inner products need no
+//    normalisation (see the interval discipline in fp29.h).
+//  * Every function documents the interval it needs; tests/hostsim proves them with -DBN_CHECK.
+#pragma once
+#include "fp29.h"
+
+namespace bn {
+
+struct Fp2 { Fp c0, c1; };
+struct Fp6 { Fp2 c0, c1, c2; };
+struct Fp12 { Fp6 c0, c1; };
+
+// ------------------------------------------------------------------ Fp2
+BN_INL Fp2 fp2_add(const Fp2& a, const Fp2& b) { return {fp_add(a.c0, b.c0), fp_add(a.c1, b.c1)}; }
+BN_INL Fp2 fp2_sub(const Fp2& a, const Fp2& b) { return {fp_sub(a.c0, b.c0), fp_sub(a.c1, b.c1)}; }
+BN_INL Fp2 fp2_neg(const Fp2& a) { return {fp_neg(a.c0), fp_neg(a.c1)}; }
+BN_INL Fp2 fp2_dbl(const Fp2& a) { return {fp_dbl(a.c0), fp_dbl(a.c1)}; }
+BN_INL Fp2 fp2_conj(const Fp2& a) { return {a.c0, fp_neg(a.c1)}; }
+BN_INL Fp2 fp2_norm(const Fp2& a) { return {fp_norm(a.c0), fp_norm(a.c1)}; }
+BN_INL Fp2 fp2_zero() { return {fp_zero(), fp_zero()}; }
+BN_INL Fp2 fp2_one() { return {fp_one(), fp_zero()}; }
+BN_INL Fp2 fp2_const(const int32_t (&c)[2 * NL]) {
+  Fp2 r;
+  BN_UNROLL for (int i = 0; i < NL; ++i) { r.c0.l[i] = c[i]; r.c1.l[i] = c[NL + i]; }
+  BN_TRK(set_trk(r.c0, 0, 1, 0, 0.006, 1); set_trk(r.c1, 0, 1, 0, 0.006, 1);)
+  return r;
+}
+BN_INL Fp2 fp2_from_limbs(const int32_t* c) { return {fp_from_limbs(c), fp_from_limbs(c + NL)}; }
+BN_INL Fp2 fp2_select(bool cond, const Fp2& a, const Fp2& b) { return {fp_select(cond, a.c0, b.c0), fp_select(cond, a.c1, b.c1)}; }
+// needs mag(a)*mag(b) <= 1.27 per component pair
+BN_INL Fp2 fp2_mul(const Fp2& a, const Fp2& b) {
+  BN_CTX;
+  Fp na1 = fp_neg(a.c1);
+  return {fp_dot2(a.c0, b.c0, na1, b.c1), fp_dot2(a.c0, b.c1, a.c1, b.c0)};
+}
+// complex squaring; needs a in [0, 1.2] limb-wise (non-negative), i.e. a multiply output or fp_norm
+BN_INL Fp2 fp2_sqr(const Fp2& a) {
+  BN_CTX;
+  return {fp_mul(fp_add(a.c0, a.c1), fp_sub(a.c0, a.c1)), fp_mul(fp_dbl(a.c0), a.c1)};
+}
+BN_INL Fp2 fp2_mul_fp(const Fp2& a, const Fp& s) { return {fp_mul(a.c0, s), fp_mul(a.c1, s)}; }
+// (9+u)(a0 + a1 u) = (9 a0 - a1) + (a0 + 9 a1) u ; normalised output
+BN_INL Fp2 fp2_mul_xi(const Fp2& a) { return {fp_lc2<9, -1>(a.c0, a.c1), fp_lc2<1, 9>(a.c0, a.c1)}; }
+// x + xi*y, normalised
+BN_INL Fp2 fp2_add_mul_xi(const Fp2& x, const Fp2& y) {
+  return {fp_lc3<1, 9, -1>(x.c0, y.c0, y.c1), fp_lc3<1, 1, 9>(x.c1, y.c0, y.c1)};
+}
+// x - xi*y, normalised
+BN_INL Fp2 fp2_sub_mul_xi(const Fp2& x, const Fp2& y) {
+  return {fp_lc3<1, -9, 1>(x.c0, y.c0, y.c1), fp_lc3<1, -1, -9>(x.c1, y.c0, y.c1)};
+}
+BN_HD inline Fp2 fp2_inv(const Fp2& a) {                                  // fp2.rs:161-166
+  Fp2 n = fp2_norm(a);
+  Fp t = fp_inv(fp_dot2(n.c0, n.c0, n.c1, n.c1));
+  return {fp_mul(n.c0, t), fp_mul(fp_neg(n.c1), t)};
+}
+BN_INL bool fp2_is_zero(const Fp2& a) { return fp_is_zero(a.c0) & fp_is_zero(a.c1); }
+BN_INL bool fp2_eq(const Fp2& a, const Fp2& b) { return fp2_is_zero(fp2_sub(a, b)); }
+BN_INL int fp2_sgn0(const Fp2& a) {                                       // fp2.rs:95-99
+  Fp c0 = fp_from_mont(a.c0), c1 = fp_from_mont(a.c1);
+  int32_t o = 0;
+  BN_UNROLL for (int i = 0; i < NL; ++i) o |= c0.l[i];
+  return (c0.l[0] & 1) | ((o == 0) & (c1.l[0] & 1));
+}
+
+// ------------------------------------------------------------------ Fp6
+BN_INL Fp6 fp6_add(const Fp6& a, const Fp6& b) { return {fp2_add(a.c0, b.c0), fp2_add(a.c1, b.c1), fp2_add(a.c2, b.c2)}; }
+BN_INL Fp6 fp6_sub(const Fp6& a, const Fp6& b) { return {fp2_sub(a.c0, b.c0), fp2_sub(a.c1, b.c1), fp2_sub(a.c2, b.c2)}; }
+BN_INL Fp6 fp6_neg(const Fp6& a) { return {fp2_neg(a.c0), fp2_neg(a.c1), fp2_neg(a.c2)}; }
+BN_INL Fp6 fp6_norm(const Fp6& a) { return {fp2_norm(a.c0), fp2_norm(a.c1), fp2_norm(a.c2)}; }
+BN_INL Fp6 fp6_zero() { return {fp2_zero(), fp2_zero(), fp2_zero()}; }
+BN_INL Fp6 fp6_one() { return {fp2_one(), fp2_zero(), fp2_zero()}; }
+// inputs normalised ([~0, ~1] limbs); output normalised.  6 Fp2 products (fp6.rs:225-242 value).
+BN_HD inline Fp6 fp6_mul(const Fp6& a, const Fp6& b) {
+  BN_CTX;
+  Fp2 v0 = fp2_mul(a.c0, b.c0), v1 = fp2_mul(a.c1, b.c1), v2 = fp2_mul(a.c2, b.c2);
+  Fp2 w0 = fp2_mul(fp2_sub(a.c1, a.c2), fp2_sub(b.c1, b.c2));
+  Fp2 w1 = fp2_mul(fp2_sub(a.c0, a.c1), fp2_sub(b.c0, b.c1));
+  Fp2 w2 = fp2_mul(fp2_sub(a.c0, a.c2), fp2_sub(b.c0, b.c2));
+  Fp2 t0 = fp2_sub(fp2_add(v1, v2), w0);        // a1 b2 + a2 b1
+  Fp2 t1 = fp2_sub(fp2_add(v0, v1), w1);        // a0 b1 + a1 b0
+  Fp2 t2 = fp2_sub(fp2_add(v0, v2), w2);        // a0 b2 + a2 b0
+  return {fp2_add_mul_xi(v0, t0), fp2_add_mul_xi(t1, v2), fp2_norm(fp2_add(t2, v1))};
+}
+BN_HD inline Fp6 fp6_sqr(const Fp6& a) { return fp6_mul(a, a); }
+BN_INL Fp6 fp6_mul_v(const Fp6& a) { return {fp2_mul_xi(a.c2), a.c0, a.c1}; }      // fp6.rs:146-152
+BN_INL Fp6 fp6_mul_fp2(const Fp6& a, const Fp2& s) { return {fp2_mul(a.c0, s), fp2_mul(a.c1, s), fp2_mul(a.c2, s)}; }
+// a * (c0 + c1 v), fp6.rs:131-144 value; inputs and output normalised
+BN_HD inline Fp6 fp6_mul_by_01(const Fp6& a, const Fp2& c0, const Fp2& c1) {
+  BN_CTX;
+  Fp2 aa = fp2_mul(a.c0, c0), bb = fp2_mul(a.c1, c1);
+  Fp2 cc = fp2_mul(a.c2, c1), dd = fp2_mul(a.c2, c0);
+  Fp2 w = fp2_mul(fp2_sub(a.c0, a.c1), fp2_sub(c0, c1));     // a0c0 + a1c1 - a0c1 - a1c0
+  Fp2 t2 = fp2_sub(fp2_add(aa, bb), w);                       // a0 c1 + a1 c0
+  return {fp2_add_mul_xi(aa, cc), fp2_norm(t2), fp2_norm(fp2_add(dd, bb))};
+}
+BN_HD inline Fp6 fp6_inv(const Fp6& a) {                       // fp6.rs:261-287 (denominator corrected)
+  Fp2 s0 = fp2_sqr(a.c0), s1 = fp2_sqr(a.c1), s2 = fp2_sqr(a.c2);
+  Fp2 m01 = fp2_mul(a.c0, a.c1), m02 = fp2_mul(a.c0, a.c2), m12 = fp2_mul(a.c1, a.c2);
+  Fp2 c0 = fp2_sub_mul_xi(s0, m12);
+  Fp2 c1 = fp2_norm(fp2_sub(fp2_mul_xi(s2), m01));
+  Fp2 c2 = fp2_norm(fp2_sub(s1, m02));
+  Fp2 u = fp2_add(fp2_mul(a.c2, c1), fp2_mul(a.c1, c2));
+  Fp2 t = fp2_inv(fp2_add_mul_xi(fp2_mul(a.c0, c0), u));
+  return {fp2_mul(c0, t), fp2_mul(c1, t), fp2_mul(c2, t)};
+}
+
+// ------------------------------------------------------------------ Fp12
+BN_INL Fp12 fp12_one() { return {fp6_one(), fp6_zero()}; }
+BN_INL Fp12 fp12_conj(const Fp12& a) { return {a.c0, fp6_norm(fp6_neg(a.c1))}; }            // fp12.rs:131-137
+// x + v*y for Fp6 x, y ; normalised
+BN_INL Fp6 fp6_add_mul_v(const Fp6& x, const Fp6& y) {
+  BN_CTX;
+  return {fp2_add_mul_xi(x.c0, y.c2), fp2_norm(fp2_add(x.c1, y.c0)), fp2_norm(fp2_add(x.c2, y.c1))};
+}
+BN_HD inline Fp12 fp12_mul(const Fp12& a, const Fp12& b) {     // fp12.rs:203-210 value
+  Fp6 v0 = fp6_mul(a.c0, b.c0), v1 = fp6_mul(a.c1, b.c1);
+  Fp6 w = fp6_mul(fp6_norm(fp6_sub(a.c0, a.c1)), fp6_norm(fp6_sub(b.c1, b.c0)));   // a0b1 + a1b0 - v0 - v1
+  return {fp6_add_mul_v(v0, v1), fp6_norm(fp6_add(fp6_add(w, v0), v1))};
+}
+BN_HD inline Fp12 fp12_sqr(const Fp12& a) {                    // complex squaring, fp12.rs:170-180 value
+  Fp6 ab = fp6_mul(a.c0, a.c1);
+  Fp6 s1 = fp6_norm(fp6_add(a.c0, a.c1));
+  Fp6 s2 = fp6_add_mul_v(a.c0, a.c1);
+  Fp6 t = fp6_mul(s1, s2);                                     // a0^2 + v a1^2 + (1+v) ab
+  Fp6 tm = fp6_sub(t, ab);
+  Fp12 r;
+  r.c0 = {fp2_sub_mul_xi(tm.c0, ab.c2), fp2_norm(fp2_sub(tm.c1, ab.c0)), fp2_norm(fp2_sub(tm.c2, ab.c1))};
+  r.c1 = fp6_norm(fp6_add(ab, ab));
+  return r;
+}
+BN_HD inline Fp12 fp12_inv(const Fp12& a) {                    // fp12.rs:212-219
+  Fp6 s0 = fp6_sqr(a.c0), s1 = fp6_sqr(a.c1);
+  Fp6 d = {fp2_sub_mul_xi(s0.c0, s1.c2), fp2_norm(fp2_sub(s0.c1, s1.c0)), fp2_norm(fp2_sub(s0.c2, s1.c1))};
+  Fp6 t = fp6_inv(d);
+  return {fp6_mul(a.c0, t), fp6_norm(fp6_neg(fp6_mul(a.c1, t)))};
+}
+// f * (o0 + o3 w + o4 w^3): sparse multiply for D-type twist lines (E7).  13 Fp2 products.
+BN_HD inline Fp12 fp12_mul_by_034(const Fp12& f, const Fp2& o0, const Fp2& o3, const Fp2& o4) {
+  BN_CTX;
+  Fp6 a = fp6_mul_fp2(f.c0, o0);
+  Fp6 b = fp6_mul_by_01(f.c1, o3, o4);
+  // (f0 + f1)(o0 + o3, o4) - a - b, computed subtractively: e = (f0 - f1)*(o3 - o0, o4) ... keep it
+  // simple: normalise the two sums (their limbs are non-negative) and use mul_by_01.
+  Fp6 e = fp6_mul_by_01(fp6_norm(fp6_add(f.c0, f.c1)), fp2_norm(fp2_add(o0, o3)), o4);
+  return {fp6_add_mul_v(a, b), fp6_norm(fp6_sub(fp6_sub(e, a), b))};
+}
+// Frobenius^k, k = 1..3: coefficient of w^i -> conj^k(.) * xi^(i (p^k-1)/6)   (E3 fixed)
+template <int K>
+BN_HD inline Fp12 fp12_frob(const Fp12& a) {
+  BN_CTX;
+  // tower slot -> w index: c0.c0=0 c1.c0=1 c0.c1=2 c1.c1=3 c0.c2=4 c1.c2=5
+  const Fp2* s[6] = {&a.c0.c0, &a.c1.c0, &a.c0.c1, &a.c1.c1, &a.c0.c2, &a.c1.c2};
+  Fp2 o[6];
+  BN_UNROLL for (int i = 0; i < 6; ++i) {
+    Fp2 c = *s[i];
+    if (K & 1) c = fp2_norm(fp2_conj(c));
+    if (i > 0) {
+      if (K == 1) c = fp2_mul(c, fp2_const(bnc::GAMMA1[i - 1]));
+      if (K == 2) c = fp2_mul_fp(c, fp_const(bnc::GAMMA2[i - 1]));
+      if (K == 3) c = fp2_mul(c, fp2_const(bnc::GAMMA3[i - 1]));
+    }
+    o[i] = c;
+  }
+  return {{o[0], o[2], o[4]}, {o[1], o[3], o[5]}};
+}
+BN_INL void fp4_square(Fp2& c0, Fp2& c1, const Fp2& a, const Fp2& b) {      // pairings.rs:52-63
+  Fp2 t0 = fp2_sqr(a), t1 = fp2_sqr(b);
+  c0 = fp2_add_mul_xi(t0, t1);
+  Fp2 ab = fp2_mul(a, b);                                       // (a+b)^2 - a^2 - b^2 = 2ab
+  c1 = fp2_norm(fp2_dbl(ab));
+}
+// Granger-Scott squaring in the cyclotomic subgroup, pairings.rs:68-115 (valid with xi = 9+u)
+BN_HD inline Fp12 fp12_cyclotomic_sqr(const Fp12& f) {
+  BN_CTX;
+  Fp2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
+  Fp2 t0, t1, t2, t3, t4, t5;
+  fp4_square(t0, t1, z0, z1);
+  fp4_square(t2, t3, z2, z3);
+  fp4_square(t4, t5, z4, z5);
+  // z0 = 3 t0 - 2 z0 ; z1 = 3 t1 + 2 z1
+  Fp2 r0 = {fp_lc2<3, -2>(t0.c0, z0.c0), fp_lc2<3, -2>(t0.c1, z0.c1)};
+  Fp2 r1 = {fp_lc2<3, 2>(t1.c0, z1.c0), fp_lc2<3, 2>(t1.c1, z1.c1)};
+  // z4 = 3 t2 - 2 z4 ; z5 = 3 t3 + 2 z5
+  Fp2 r4 = {fp_lc2<3, -2>(t2.c0, z4.c0), fp_lc2<3, -2>(t2.c1, z4.c1)};
+  Fp2 r5 = {fp_lc2<3, 2>(t3.c0, z5.c0), fp_lc2<3, 2>(t3.c1, z5.c1)};
+  // z2 = 3 xi t5 + 2 z2 ; z3 = 3 t4 - 2 z3
+  Fp2 xt = fp2_mul_xi(t5);
+  Fp2 r2 = {fp_lc2<3, 2>(xt.c0, z2.c0), fp_lc2<3, 2>(xt.c1, z2.c1)};
+  Fp2 r3 = {fp_lc2<3, -2>(t4.c0, z3.c0), fp_lc2<3, -2>(t4.c1, z3.c1)};
+  return {{r0, r4, r3}, {r2, r1, r5}};
+}
+BN_INL bool fp12_is_one(const Fp12& a) {
+  bool z = fp_is_zero(fp_sub(a.c0.c0.c0, fp_one()));
+  z &= fp_is_zero(a.c0.c0.c1);
+  z &= fp2_is_zero(a.c0.c1) & fp2_is_zero(a.c0.c2);
+  z &= fp2_is_zero(a.c1.c0) & fp2_is_zero(a.c1.c1) & fp2_is_zero(a.c1.c2);
+  return z;
+}
+
+}  // namespace bn

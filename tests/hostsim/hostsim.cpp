@@ -1,0 +1,93 @@
+// hostsim.cpp -- compiles the DEVICE arithmetic headers (bls-bn254_amd/csrc/*.h) for the host with
+// -DBN_CHECK: every Fp then carries its proven limb interval / value bound and every multiply asserts
+// its precondition (fp29.h "interval discipline").  Used by tests/test_hostsim.py to (1) prove the
+// lazy-limb bounds of every code path the kernels run and (2) compare that code with the oracle
+// without a GPU.  TEST TOOL ONLY: never linked into the product.
+#define BN_WANT_LINE_TABLE
+#define BN_LINE_TABLE_QUAL static const
+#include "../../bls-bn254_amd/csrc/lane_ops.h"
+#include <cstring>
+
+using namespace bn;
+
+extern "C" {
+
+void hs_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  bool o1, o2;
+  Fp x = fp_from_be(a, o1), y = fp_from_be(b, o2);
+  fp_to_be(out, fp_mul(x, y));
+}
+void hs_fp_sqr(const uint8_t* a, uint8_t* out) { bool o; Fp x = fp_from_be(a, o); fp_to_be(out, fp_sqr(x)); }
+void hs_fp_inv(const uint8_t* a, uint8_t* out) { bool o; Fp x = fp_from_be(a, o); fp_to_be(out, fp_inv(x)); }
+// ((a+b)*(a-b) + 9a - b) exercising lazy ops
+void hs_fp_mix(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  bool o1, o2;
+  Fp x = fp_from_be(a, o1), y = fp_from_be(b, o2);
+  Fp t = fp_mul(fp_add(x, y), fp_sub(x, y));
+  fp_to_be(out, fp_lc3<1, 9, -1>(t, x, y));
+}
+int hs_fp_decode_ok(const uint8_t* a) { bool o; (void)fp_from_be(a, o); return o; }
+void hs_fp_from_okm(const uint8_t* okm, uint8_t* out) { fp_to_be(out, fp_from_okm(okm)); }
+
+void hs_miller1(const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* status) {
+  uint8_t st;
+  Fp12 f = lane_miller_1(g1, g2, bnc::ATE_NAF, bnc::ATE_NAF_LEN, st);
+  *status = st;
+  fp12_to_be(out, f);
+}
+int hs_final_exp(const uint8_t* in, uint8_t* out) {
+  bool ok;
+  Fp12 f = fp12_from_be(in, ok);
+  if (!ok) return 4;
+  fp12_to_be(out, final_exponentiation(f));
+  return 0;
+}
+void hs_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* out) {
+  uint8_t st;
+  Fp12 f = lane_miller_1(g1, g2, bnc::ATE_NAF, bnc::ATE_NAF_LEN, st);
+  fp12_to_be(out, final_exponentiation(f));
+}
+void hs_fp12_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  bool o1, o2;
+  Fp12 x = fp12_from_be(a, o1), y = fp12_from_be(b, o2);
+  fp12_to_be(out, fp12_mul(x, y));
+}
+void hs_hash_to_g1(const uint8_t* msg, size_t len, const uint8_t* dst, uint32_t dst_len, int ro, uint8_t* out) {
+  G1A h = ro ? lane_hash_to_g1(msg, len, dst, dst_len) : lane_encode_to_g1(msg, len, dst, dst_len);
+  g1_encode(out, h);
+}
+void hs_hash_to_g2(const uint8_t* msg, size_t len, const uint8_t* dst, uint32_t dst_len, int ro, uint8_t* out) {
+  g2_encode(out, lane_hash_to_g2(msg, len, dst, dst_len, ro != 0));
+}
+int hs_g1_check(const uint8_t* g1) { return lane_g1_check(g1); }
+int hs_g2_check(const uint8_t* g2) { return lane_g2_check(g2); }
+void hs_g1_add(const uint8_t* a, const uint8_t* b, uint8_t* out) {
+  bool o1, o2;
+  G1A p = g1_decode(a, o1), q = g1_decode(b, o2);
+  g1_encode(out, g1_to_affine(proj_add(proj_from_affine(p), proj_from_affine(q))));
+}
+void hs_g1_mul(const uint8_t* a, const uint8_t* k_be, uint8_t* out) {
+  bool o1;
+  G1A p = g1_decode(a, o1);
+  uint64_t k[4];
+  for (int i = 0; i < 4; ++i) { uint64_t v = 0; for (int j = 0; j < 8; ++j) v = (v << 8) | k_be[8 * (3 - i) + j]; k[i] = v; }
+  g1_encode(out, g1_to_affine(proj_mul_256(proj_from_affine(p), k)));
+}
+// full single verify as the kernels compose it
+int hs_verify(const uint8_t* pk, const uint8_t* msg, size_t len, const uint8_t* sig, const uint8_t* dst, uint32_t dst_len,
+              uint8_t* ml_out) {
+  G1A h = lane_hash_to_g1(msg, len, dst, dst_len);
+  uint8_t flags;
+  Fp12 f = lane_miller_verify(pk, sig, h, bnc::ATE_NAF, bnc::ATE_NAF_LEN, BN_NEG_G2_LINE_TABLE, flags);
+  if (ml_out) fp12_to_be(ml_out, f);
+  bool sub = lane_g2_check(pk);
+  bool one = fp12_is_one(final_exponentiation(f));
+  return (flags == (FLAG_SIG_OK | FLAG_PK_OK)) && sub && one;
+}
+void hs_stats(double* out) {
+  CheckStats& s = check_stats();
+  out[0] = s.worst_mul; out[1] = s.worst_dot; out[2] = s.worst_vb;
+  out[3] = (double)s.muls; out[4] = (double)s.sqrs; out[5] = (double)s.dots; out[6] = (double)s.norms; out[7] = (double)s.lcs;
+}
+void hs_stats_reset() { check_stats() = CheckStats(); }
+}
