@@ -248,13 +248,13 @@ BN_HD inline G1A hash_to_g1_from_fields(const Fp& u0, const Fp& u1) {
 }
 
 // Fp2 helpers for the G2 map
-BN_HD inline Fp2 fp2_pow(const Fp2& a, const uint64_t (&e)[4]) {
+BN_HD inline Fp2 fp2_pow(const Fp2& a, Exp256 e) {
   BN_CTX;
   Fp2 base = fp2_norm(a), r = fp2_one();
   for (int i = 255; i >= 0; --i) {
     r = fp2_sqr(r);
     Fp2 m = fp2_mul(r, base);
-    r = fp2_select((e[i >> 6] >> (i & 63)) & 1, m, r);
+    r = fp2_select((e.w[i >> 6] >> (i & 63)) & 1, m, r);
   }
   return r;
 }
@@ -268,12 +268,12 @@ BN_HD inline bool fp2_is_square(const Fp2& a) {                  // fp2.rs:441-4
 BN_HD inline Fp2 fp2_sqrt(const Fp2& a_in) {
   BN_CTX;
   Fp2 a = fp2_norm(a_in);
-  Fp2 a1 = fp2_pow(a, bnc::EXP_PM3_4);
+  Fp2 a1 = fp2_pow(a, BN_EXP(EXP_PM3_4));
   Fp2 alpha = fp2_mul(fp2_sqr(a1), a);
   Fp2 x0 = fp2_mul(a1, a);
   bool neg_one = fp2_is_zero(fp2_add(alpha, fp2_one()));
   Fp2 alt = {fp_norm(fp_neg(x0.c1)), x0.c0};
-  Fp2 b = fp2_pow(fp2_norm(fp2_add(alpha, fp2_one())), bnc::EXP_PM1_2);
+  Fp2 b = fp2_pow(fp2_norm(fp2_add(alpha, fp2_one())), BN_EXP(EXP_PM1_2));
   Fp2 r = fp2_mul(b, x0);
   return fp2_select(neg_one, alt, r);
 }

@@ -403,7 +403,9 @@ BN_INL Fp fp_from_okm(const uint8_t* okm) {
 // ------------------------------------------------------------------ exponentiation helpers
 // a^e for a fixed public 256-bit exponent (uniform control flow: every lane runs the same bits).
 // 4-bit fixed windows: 252 squarings + 64 multiplies + 14 table products.
-BN_HD inline Fp fp_pow(const Fp& a, const uint64_t (&e)[4]) {
+struct Exp256 { uint64_t w[4]; };
+#define BN_EXP(name) (::bn::Exp256{{bnc::name[0], bnc::name[1], bnc::name[2], bnc::name[3]}})
+BN_HD inline Fp fp_pow(const Fp& a, Exp256 e) {
   Fp tab[16];
   tab[0] = fp_one();
   tab[1] = fp_norm(a);
@@ -411,16 +413,16 @@ BN_HD inline Fp fp_pow(const Fp& a, const uint64_t (&e)[4]) {
   Fp r = fp_one();
   for (int w = 63; w >= 0; --w) {
     if (w != 63) { r = fp_sqr(r); r = fp_sqr(r); r = fp_sqr(r); r = fp_sqr(r); }
-    int d = (int)((e[w >> 4] >> ((w & 15) * 4)) & 15);
+    int d = (int)((e.w[w >> 4] >> ((w & 15) * 4)) & 15);
     if (w == 63) r = tab[d]; else if (d) r = fp_mul(r, tab[d]);
   }
   return r;
 }
-BN_HD inline Fp fp_inv(const Fp& a) { return fp_pow(a, bnc::EXP_PM2); }                 // inv0(0) = 0 (E15)
+BN_HD inline Fp fp_inv(const Fp& a) { return fp_pow(a, BN_EXP(EXP_PM2)); }                 // inv0(0) = 0 (E15)
 // y = a^((p+1)/4); is_sq = (y^2 == a).  One exponentiation gives Euler's criterion (fp.rs:428-431)
 // and the square root (sqrt_ratio with v = 1, fp.rs:212-243) together.
 BN_HD inline Fp fp_sqrt_cand(const Fp& a, bool& is_sq) {
-  Fp y = fp_pow(a, bnc::EXP_PP1_4);
+  Fp y = fp_pow(a, BN_EXP(EXP_PP1_4));
   is_sq = fp_eq(fp_sqr(y), a);
   return y;
 }

@@ -1,0 +1,641 @@
+// kernels.hip -- HIP kernels (gfx950) and the C-ABI host side of the BLS-BN254 verification engine.
+//
+// One lane = one tuple.  The hot path is split into phase kernels whose per-tuple state lives in HBM
+// in limb-major layout (ws[k * n + i]: coalesced 256-B wave accesses), because the live state of a
+// phase (f in Fp12 = 108 dwords, T = 54, line = 54, ...) exceeds what can stay in registers across
+// phases at two waves per SIMD; the HBM traffic this costs is ~1 KB per tuple per phase against
+// millions of VALU operations (DESIGN.md "Roofline").
+//
+//   k_hash_to_g1      msgs -> H(msg) (XMD-SHA-256 + 2x SVDW + add)          g1.rs:910-919
+//   k_g2_check        pk   -> decodes && on curve && in the r-torsion        g2.rs:350-414,:733-736
+//   k_miller_verify   (sig, H, pk) -> f = ML(sig,-G2gen) * ML(H,pk)          pairings.rs:808-857
+//   k_final_exp       f -> f^((p^12-1)/r * 2x(6x^2+3x+1)); == 1 -> bitmap   pairings.rs:50-178
+//   k_miller_1, k_fp12_* , k_g1_* ...  the primitive / aggregate / threshold entry points
+//
+// There is no CPU fallback in this file: every entry point launches kernels or fails.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#define BN_WANT_LINE_TABLE
+#define BN_LINE_TABLE_QUAL __device__ const
+#include "lane_ops.h"
+#include "fr29.h"
+#include "../../include/blsbn254.h"
+
+using namespace bn;
+
+#ifndef BN_WAVES_PER_SIMD
+#define BN_WAVES_PER_SIMD 1
+#endif
+#define BN_KERNEL __global__ void __launch_bounds__(256, BN_WAVES_PER_SIMD)
+
+__device__ const int8_t d_ate_naf[bnc::ATE_NAF_LEN] = BN_ATE_NAF_INIT;
+
+// ------------------------------------------------------------------ kernels
+// ok bit per tuple -> LSB-first bitmap, one 64-bit ballot per wave
+__device__ inline void write_ballot(uint8_t* bitmap, size_t n, size_t i, bool bit) {
+  unsigned long long m = __ballot(bit);
+  unsigned lane = threadIdx.x & 63;
+  size_t base = (i - lane) >> 3;                       // first byte of this wave's 64 tuples
+  size_t nbytes = (n + 7) >> 3;
+  if (lane < 8 && base + lane < nbytes) bitmap[base + lane] = (uint8_t)(m >> (8 * lane));
+}
+
+// mode: 0 = hash (RO) -> 18 limbs into h_ws ; 1 = hash -> 64 bytes ; 2 = encode (NU) -> 64 bytes
+BN_KERNEL k_hash_to_g1(const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
+                       int32_t* h_ws, uint8_t* out_bytes, int mode) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* m = msgs + off[i];
+  size_t len = (size_t)(off[i + 1] - off[i]);
+  G1A h = mode == 2 ? lane_encode_to_g1(m, len, dst, dst_len) : lane_hash_to_g1(m, len, dst, dst_len);
+  if (mode == 0) { store_fp(h_ws + i, n, h.x); store_fp(h_ws + 9 * n + i, n, h.y); }
+  else g1_encode(out_bytes + 64 * i, h);
+}
+BN_KERNEL k_hash_to_g2(const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
+                       uint8_t* out_bytes, int ro) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g2_encode(out_bytes + 128 * i, lane_hash_to_g2(msgs + off[i], (size_t)(off[i + 1] - off[i]), dst, dst_len, ro != 0));
+}
+BN_KERNEL k_g1_check(const uint8_t* g1, size_t n, uint8_t* bitmap) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = i < n ? lane_g1_check(g1 + 64 * i) : false;
+  write_ballot(bitmap, n, i, ok);
+}
+// out: byte per tuple (ok_bytes) and/or bitmap
+BN_KERNEL k_g2_check(const uint8_t* g2, size_t n, uint8_t* ok_bytes, uint8_t* bitmap) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = i < n ? lane_g2_check(g2 + 128 * i) : false;
+  if (ok_bytes && i < n) ok_bytes[i] = ok;
+  if (bitmap) write_ballot(bitmap, n, i, ok);
+}
+// per-pair Miller loop; P either 64 bytes (g1) or 18 limbs in p_ws (then p_ok taken from p_flags)
+BN_KERNEL k_miller_1(const uint8_t* g1, const uint8_t* g2, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint8_t st;
+  Fp12 f = lane_miller_1(g1 + 64 * i, g2 + 128 * i, d_ate_naf, bnc::ATE_NAF_LEN, st);
+  fp12_store_limbs(f_ws + i, f_stride, f);
+  status[i] = st;
+}
+// aggregate verify: P = H(msg_i) from h_ws, Q = pk_i; flags: bit0 pk decodes/on curve/non-identity
+BN_KERNEL k_miller_hpk(const int32_t* h_ws, const uint8_t* pks, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* flags) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool okp;
+  G2A pk = g2_decode(pks + 128 * i, okp);
+  bool pk_ok = okp & !pk.inf & g2_on_curve(pk);
+  pk.x = fp2_select(pk_ok, pk.x, fp2_const(bnc::G2_GEN_X)); pk.y = fp2_select(pk_ok, pk.y, fp2_const(bnc::G2_GEN_Y));
+  pk.inf = false;
+  G1A h; h.x = load_fp(h_ws + i, n); h.y = load_fp(h_ws + 9 * n + i, n); h.inf = false;
+  fp12_store_limbs(f_ws + i, f_stride, miller_loop_1(h, pk, d_ate_naf, bnc::ATE_NAF_LEN));
+  flags[i] = pk_ok ? 1 : 0;
+}
+BN_KERNEL k_miller_verify(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n, int32_t* f_ws, uint8_t* flags) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1A h; h.x = load_fp(h_ws + i, n); h.y = load_fp(h_ws + 9 * n + i, n); h.inf = false;
+  uint8_t fl;
+  Fp12 f = lane_miller_verify(pks + 128 * i, sigs + 64 * i, h, d_ate_naf, bnc::ATE_NAF_LEN, BN_NEG_G2_LINE_TABLE, fl);
+  fp12_store_limbs(f_ws + i, n, f);
+  flags[i] = fl;
+}
+// mode 0: verify -> bitmap bit = flags ok && subgroup ok && FE(f) == 1
+// mode 1: pairing -> gt bytes (identity status -> one); mode 2: plain final exponentiation -> bytes
+BN_KERNEL k_final_exp(const int32_t* f_ws, size_t n, size_t f_stride, const uint8_t* flags, const uint8_t* sub_ok,
+                      uint8_t* bitmap, uint8_t* gt_bytes, int mode) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool bit = false;
+  if (i < n) {
+    Fp12 f = final_exponentiation(fp12_load_limbs(f_ws + i, f_stride));
+    if (mode == 0) bit = fp12_is_one(f) & (flags[i] == (FLAG_SIG_OK | FLAG_PK_OK)) & (sub_ok[i] != 0);
+    else fp12_to_be(gt_bytes + 384 * i, f);
+  }
+  if (mode == 0) write_ballot(bitmap, n, i, bit);
+}
+BN_KERNEL k_fp12_from_bytes(const uint8_t* in, size_t n, int32_t* f_ws, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool ok;
+  Fp12 f = fp12_from_be(in + 384 * i, ok);
+  fp12_store_limbs(f_ws + i, n, f);
+  status[i] = ok ? 1 : 0;
+}
+BN_KERNEL k_fp12_to_bytes(const int32_t* f_ws, size_t n, size_t stride, uint8_t* out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fp12_to_be(out + 384 * i, fp12_load_limbs(f_ws + i, stride));
+}
+// product tree level: out[i] = in[2i] * in[2i+1] (or in[2i] when 2i+1 == n_in)
+BN_KERNEL k_fp12_mul_pairs(const int32_t* in, size_t n_in, size_t in_stride, int32_t* out, size_t out_stride) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t n_out = (n_in + 1) >> 1;
+  if (i >= n_out) return;
+  Fp12 a = fp12_load_limbs(in + 2 * i, in_stride);
+  if (2 * i + 1 < n_in) a = fp12_mul(a, fp12_load_limbs(in + 2 * i + 1, in_stride));
+  fp12_store_limbs(out + i, out_stride, a);
+}
+// G1 sums (aggregate_sigs, threshold_combine): projective points as 27 limbs, limb-major
+__device__ inline void store_g1p(int32_t* ws, size_t stride, const G1P& p) {
+  store_fp(ws, stride, p.x); store_fp(ws + 9 * stride, stride, p.y); store_fp(ws + 18 * stride, stride, p.z);
+}
+__device__ inline G1P load_g1p(const int32_t* ws, size_t stride) {
+  return {load_fp(ws, stride), load_fp(ws + 9 * stride, stride), load_fp(ws + 18 * stride, stride)};
+}
+// scalars: NULL (plain load) or n x 32 B big-endian (threshold: lambda_i * sig_i)
+BN_KERNEL k_g1_load(const uint8_t* g1, const uint8_t* scalars, size_t n, int32_t* ws, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool ok;
+  G1A a = g1_decode(g1 + 64 * i, ok);
+  G1P p = proj_from_affine(a);
+  if (scalars) {
+    uint64_t k[4];
+    for (int w = 0; w < 4; ++w) {
+      uint64_t v = 0;
+      for (int j = 0; j < 8; ++j) v = (v << 8) | scalars[32 * i + 8 * (3 - w) + j];
+      k[w] = v;
+    }
+    p = proj_mul_256(p, k);
+  }
+  store_g1p(ws + i, n, p);
+  status[i] = ok ? 1 : 0;
+}
+BN_KERNEL k_g1_add_pairs(const int32_t* in, size_t n_in, size_t in_stride, int32_t* out, size_t out_stride) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t n_out = (n_in + 1) >> 1;
+  if (i >= n_out) return;
+  G1P a = load_g1p(in + 2 * i, in_stride);
+  if (2 * i + 1 < n_in) a = proj_add(a, load_g1p(in + 2 * i + 1, in_stride));
+  store_g1p(out + i, out_stride, a);
+}
+BN_KERNEL k_g1_to_bytes(const int32_t* ws, size_t stride, uint8_t* out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  g1_encode(out, g1_to_affine(load_g1p(ws, stride)));
+}
+// threshold: lane i -> lambda_i as 32 big-endian bytes (scalars for k_g1_load); status 1 = ok
+BN_KERNEL k_lagrange(const uint8_t* ids, size_t t, uint8_t* scalars, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= t) return;
+  bool ok;
+  Fr lam = lagrange_at_zero(ids, t, i, ok);
+  fr_to_be(scalars + 32 * i, lam);
+  status[i] = ok ? 1 : 0;
+}
+// status reductions
+__global__ void k_status_reduce(const uint8_t* status, size_t n, uint8_t want_mask, uint8_t want_val, int* first_bad) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && (status[i] & want_mask) != want_val) atomicMin(first_bad, (int)(i > 0x7ffffffe ? 0x7ffffffe : i));
+}
+__global__ void k_and_reduce(const uint8_t* flags, const uint8_t* sub_ok, size_t n, int* all_ok) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && (flags[i] != 1 || sub_ok[i] == 0)) atomicAnd(all_ok, 0);
+}
+BN_KERNEL k_final_exp_is_one(const int32_t* f_ws, size_t stride, int* out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  *out = fp12_is_one(final_exponentiation(fp12_load_limbs(f_ws, stride))) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ host side
+struct DevBuf {
+  void* p = nullptr; size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+struct ProfEntry { uint64_t launches = 0; std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; double ms = 0; };
+
+struct blsbn254_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  DevBuf in_a, in_b, in_c, in_off, dst, h_ws, f_ws, f_ws2, flags, sub_ok, status, bitmap, out, scalars, misc;
+  bool profiling = false;
+  std::map<std::string, ProfEntry> prof;
+  std::string last_error;
+};
+
+#define HIPCHK(ctx, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (ctx)->last_error = std::string(#x) + ": " + hipGetErrorString(e_); \
+    return e_ == hipErrorOutOfMemory ? BLSBN254_E_NOMEM : BLSBN254_E_HIP; } } while (0)
+
+static inline unsigned nblocks(size_t n) { return (unsigned)((n + 255) / 256); }
+
+struct ProfScope {
+  blsbn254_ctx* c; const char* name; hipEvent_t e0 = nullptr, e1 = nullptr;
+  ProfScope(blsbn254_ctx* c_, const char* n) : c(c_), name(n) {
+    if (c->profiling) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, c->stream); }
+  }
+  ~ProfScope() {
+    if (c->profiling) { (void)hipEventRecord(e1, c->stream); ProfEntry& p = c->prof[name]; ++p.launches; p.pending.emplace_back(e0, e1); }
+  }
+};
+#define LAUNCH(ctx, name, kernel, n, ...) do { ProfScope ps_(ctx, name); \
+    hipLaunchKernelGGL(kernel, dim3(nblocks(n)), dim3(256), 0, (ctx)->stream, __VA_ARGS__); } while (0); HIPCHK(ctx, hipGetLastError())
+
+extern "C" {
+
+const char* blsbn254_strerror(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case 1: return "invalid scalar bytes";
+    case 2: return "invalid G1 bytes";
+    case 3: return "invalid G2 bytes";
+    case 4: return "invalid Gt bytes";
+    case BLSBN254_E_ARG: return "invalid argument";
+    case BLSBN254_E_HIP: return "HIP runtime error";
+    case BLSBN254_E_NOMEM: return "out of device memory";
+    case BLSBN254_E_NO_DEVICE: return "no gfx950 device available (there is no CPU fallback)";
+    default: return "unknown error";
+  }
+}
+const char* blsbn254_last_error(blsbn254_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int blsbn254_ctx_create(int device, blsbn254_ctx** out) {
+  if (!out) return BLSBN254_E_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return BLSBN254_E_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return BLSBN254_E_NO_DEVICE;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return BLSBN254_E_NO_DEVICE;
+  blsbn254_ctx* c = new blsbn254_ctx();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return BLSBN254_E_HIP; }
+  *out = c;
+  return 0;
+}
+void blsbn254_ctx_destroy(blsbn254_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& kv : c->prof) for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  DevBuf* bufs[] = {&c->in_a, &c->in_b, &c->in_c, &c->in_off, &c->dst, &c->h_ws, &c->f_ws, &c->f_ws2, &c->flags, &c->sub_ok, &c->status, &c->bitmap, &c->out, &c->scalars, &c->misc};
+  for (DevBuf* b : bufs) b->release();
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+int blsbn254_ctx_synchronize(blsbn254_ctx* c) { if (!c) return BLSBN254_E_ARG; HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+void* blsbn254_ctx_stream(blsbn254_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int blsbn254_profile_enable(blsbn254_ctx* c, int on) { if (!c) return BLSBN254_E_ARG; c->profiling = on != 0; return 0; }
+int blsbn254_profile_reset(blsbn254_ctx* c) {
+  if (!c) return BLSBN254_E_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (auto& kv : c->prof) for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+  c->prof.clear();
+  return 0;
+}
+int blsbn254_profile_read(blsbn254_ctx* c, char* names, uint64_t* launches, double* total_ms, int max_entries) {
+  if (!c) return BLSBN254_E_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  int k = 0;
+  for (auto& kv : c->prof) {
+    ProfEntry& p = kv.second;
+    for (auto& pr : p.pending) { float ms = 0; (void)hipEventElapsedTime(&ms, pr.first, pr.second); p.ms += ms; (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    p.pending.clear();
+    if (k < max_entries) { std::snprintf(names + 32 * k, 32, "%s", kv.first.c_str()); launches[k] = p.launches; total_ms[k] = p.ms; ++k; }
+  }
+  return k;
+}
+
+// DST handling: RFC 9380 5.3.3 (oversize DSTs are pre-hashed); staged into device memory once per call
+static int stage_dst(blsbn254_ctx* c, const uint8_t* dst, size_t dst_len, uint32_t* out_len) {
+  uint8_t tmp[256];
+  if (dst_len > 255) {
+    Sha256 s; sha256_init(s);
+    sha256_update(s, (const uint8_t*)"H2C-OVERSIZE-DST-", 17); sha256_update(s, dst, dst_len); sha256_final(s, tmp);
+    dst_len = 32;
+  } else if (dst_len) std::memcpy(tmp, dst, dst_len);
+  HIPCHK(c, c->dst.reserve(256));
+  if (dst_len) HIPCHK(c, hipMemcpyAsync(c->dst.p, tmp, dst_len, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));     // tmp is on the stack
+  *out_len = (uint32_t)dst_len;
+  return 0;
+}
+static int check_offsets(const uint64_t* off, size_t n) {
+  for (size_t i = 0; i < n; ++i) if (off[i + 1] < off[i]) return BLSBN254_E_ARG;
+  return 0;
+}
+// first index whose status differs from the wanted value, or -1
+static int first_bad(blsbn254_ctx* c, const uint8_t* d_status, size_t n, uint8_t mask, uint8_t val, int* out) {
+  HIPCHK(c, c->misc.reserve(64));
+  int init = 0x7fffffff;
+  HIPCHK(c, hipMemcpyAsync(c->misc.p, &init, 4, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "status_reduce", k_status_reduce, n, d_status, n, mask, val, (int*)c->misc.p);
+  HIPCHK(c, hipMemcpyAsync(out, c->misc.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (*out == 0x7fffffff) *out = -1;
+  return 0;
+}
+// status byte of the tuple at index idx (host read)
+static int read_status(blsbn254_ctx* c, const uint8_t* d_status, int idx, uint8_t* st) {
+  HIPCHK(c, hipMemcpyAsync(st, d_status + idx, 1, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---------------- pairing / Miller loop / final exponentiation
+static int miller_to_ws(blsbn254_ctx* c, const uint8_t* d_g1, const uint8_t* d_g2, size_t n) {
+  HIPCHK(c, c->f_ws.reserve(n * 108 * 4));
+  HIPCHK(c, c->status.reserve(n));
+  LAUNCH(c, "miller_1", k_miller_1, n, d_g1, d_g2, n, (int32_t*)c->f_ws.p, n, (uint8_t*)c->status.p);
+  return 0;
+}
+static int decode_status_rc(blsbn254_ctx* c, size_t n) {
+  int bad;
+  int rc = first_bad(c, (const uint8_t*)c->status.p, n, 3, 3, &bad);
+  if (rc) return rc;
+  if (bad < 0) return 0;
+  uint8_t st; rc = read_status(c, (const uint8_t*)c->status.p, bad, &st);
+  if (rc) return rc;
+  return (st & 1) ? BLSBN254_ERR_G2 : BLSBN254_ERR_G1;
+}
+int blsbn254_pairing_batch_dev(blsbn254_ctx* c, const uint8_t* d_g1, const uint8_t* d_g2, size_t n, uint8_t* d_gt, uint8_t* d_status) {
+  if (!c || (n && (!d_g1 || !d_g2 || !d_gt))) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = miller_to_ws(c, d_g1, d_g2, n);
+  if (rc) return rc;
+  LAUNCH(c, "final_exp", k_final_exp, n, (const int32_t*)c->f_ws.p, n, n, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr, d_gt, 1);
+  if (d_status) HIPCHK(c, hipMemcpyAsync(d_status, c->status.p, n, hipMemcpyDeviceToDevice, c->stream));
+  return 0;
+}
+int blsbn254_pairing_batch(blsbn254_ctx* c, const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t* gt) {
+  if (!c || (n && (!g1 || !g2 || !gt))) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->in_a.reserve(64 * n)); HIPCHK(c, c->in_b.reserve(128 * n)); HIPCHK(c, c->out.reserve(384 * n));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, g1, 64 * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->in_b.p, g2, 128 * n, hipMemcpyHostToDevice, c->stream));
+  int rc = blsbn254_pairing_batch_dev(c, (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_b.p, n, (uint8_t*)c->out.p, nullptr);
+  if (rc) return rc;
+  rc = decode_status_rc(c, n);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(gt, c->out.p, 384 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int blsbn254_miller_loop_batch(blsbn254_ctx* c, const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t* ml_out) {
+  if (!c || (n && (!g1 || !g2 || !ml_out))) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->in_a.reserve(64 * n)); HIPCHK(c, c->in_b.reserve(128 * n)); HIPCHK(c, c->out.reserve(384 * n));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, g1, 64 * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->in_b.p, g2, 128 * n, hipMemcpyHostToDevice, c->stream));
+  int rc = miller_to_ws(c, (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_b.p, n);
+  if (rc) return rc;
+  rc = decode_status_rc(c, n);
+  if (rc) return rc;
+  LAUNCH(c, "fp12_to_bytes", k_fp12_to_bytes, n, (const int32_t*)c->f_ws.p, n, n, (uint8_t*)c->out.p);
+  HIPCHK(c, hipMemcpyAsync(ml_out, c->out.p, 384 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+// product of the n Fp12 values in f_ws (stride n) -> left in *result (pointer into f_ws or f_ws2), stride *rs
+static int product_tree(blsbn254_ctx* c, size_t n, const int32_t** result, size_t* rs) {
+  HIPCHK(c, c->f_ws2.reserve(((n + 1) / 2) * 108 * 4));
+  int32_t* a = (int32_t*)c->f_ws.p; int32_t* b = (int32_t*)c->f_ws2.p;
+  size_t sa = n, m = n;
+  while (m > 1) {
+    size_t mo = (m + 1) / 2;
+    LAUNCH(c, "fp12_mul_pairs", k_fp12_mul_pairs, mo, (const int32_t*)a, m, sa, b, mo);
+    std::swap(a, b); sa = mo; m = mo;
+  }
+  *result = a; *rs = sa;
+  return 0;
+}
+int blsbn254_multi_miller_loop(blsbn254_ctx* c, const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t ml_out[384]) {
+  if (!c || !ml_out || (n && (!g1 || !g2))) return BLSBN254_E_ARG;
+  if (n == 0) { std::memset(ml_out, 0, 384); ml_out[31] = 1; return 0; }       // empty product = Fp12::ONE
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->in_a.reserve(64 * n)); HIPCHK(c, c->in_b.reserve(128 * n)); HIPCHK(c, c->out.reserve(384));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, g1, 64 * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->in_b.p, g2, 128 * n, hipMemcpyHostToDevice, c->stream));
+  int rc = miller_to_ws(c, (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_b.p, n);
+  if (rc) return rc;
+  rc = decode_status_rc(c, n);
+  if (rc) return rc;
+  const int32_t* res; size_t rs;
+  rc = product_tree(c, n, &res, &rs);
+  if (rc) return rc;
+  LAUNCH(c, "fp12_to_bytes", k_fp12_to_bytes, 1, res, (size_t)1, rs, (uint8_t*)c->out.p);
+  HIPCHK(c, hipMemcpyAsync(ml_out, c->out.p, 384, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int blsbn254_final_exponentiation(blsbn254_ctx* c, const uint8_t* ml, size_t n, uint8_t* gt) {
+  if (!c || (n && (!ml || !gt))) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->in_a.reserve(384 * n)); HIPCHK(c, c->out.reserve(384 * n)); HIPCHK(c, c->f_ws.reserve(n * 108 * 4)); HIPCHK(c, c->status.reserve(n));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, ml, 384 * n, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "fp12_from_bytes", k_fp12_from_bytes, n, (const uint8_t*)c->in_a.p, n, (int32_t*)c->f_ws.p, (uint8_t*)c->status.p);
+  int bad; int rc = first_bad(c, (const uint8_t*)c->status.p, n, 1, 1, &bad);
+  if (rc) return rc;
+  if (bad >= 0) return BLSBN254_ERR_GT;
+  LAUNCH(c, "final_exp", k_final_exp, n, (const int32_t*)c->f_ws.p, n, n, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)c->out.p, 2);
+  HIPCHK(c, hipMemcpyAsync(gt, c->out.p, 384 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+// ---------------- hash to curve
+static int stage_msgs(blsbn254_ctx* c, const uint8_t* msgs, const uint64_t* off, size_t n) {
+  if (check_offsets(off, n)) return BLSBN254_E_ARG;
+  size_t total = (size_t)(off[n] - off[0]);
+  HIPCHK(c, c->in_c.reserve(total + 1)); HIPCHK(c, c->in_off.reserve(8 * (n + 1)));
+  if (total) HIPCHK(c, hipMemcpyAsync(c->in_c.p, msgs + off[0], total, hipMemcpyHostToDevice, c->stream));
+  if (off[0] == 0) HIPCHK(c, hipMemcpyAsync(c->in_off.p, off, 8 * (n + 1), hipMemcpyHostToDevice, c->stream));
+  else {
+    std::vector<uint64_t> rel(n + 1);
+    for (size_t i = 0; i <= n; ++i) rel[i] = off[i] - off[0];
+    HIPCHK(c, hipMemcpyAsync(c->in_off.p, rel.data(), 8 * (n + 1), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return 0;
+}
+static int h2c_common(blsbn254_ctx* c, const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* out, int g2, int ro) {
+  if (!c || (n && (!msgs && off && off[n] != off[0])) || !off || (n && !out) || (dst_len && !dst)) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
+  if (rc) return rc;
+  rc = stage_msgs(c, msgs, off, n);
+  if (rc) return rc;
+  size_t sz = g2 ? 128 : 64;
+  HIPCHK(c, c->out.reserve(sz * n));
+  if (g2) { LAUNCH(c, "hash_to_g2", k_hash_to_g2, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (uint8_t*)c->out.p, ro); }
+  else { LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (int32_t*)nullptr, (uint8_t*)c->out.p, ro ? 1 : 2); }
+  HIPCHK(c, hipMemcpyAsync(out, c->out.p, sz * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int blsbn254_hash_to_g1_batch(blsbn254_ctx* c, const uint8_t* m, const uint64_t* o, size_t n, const uint8_t* d, size_t dl, uint8_t* out) { return h2c_common(c, m, o, n, d, dl, out, 0, 1); }
+int blsbn254_encode_to_g1_batch(blsbn254_ctx* c, const uint8_t* m, const uint64_t* o, size_t n, const uint8_t* d, size_t dl, uint8_t* out) { return h2c_common(c, m, o, n, d, dl, out, 0, 0); }
+int blsbn254_hash_to_g2_batch(blsbn254_ctx* c, const uint8_t* m, const uint64_t* o, size_t n, const uint8_t* d, size_t dl, uint8_t* out) { return h2c_common(c, m, o, n, d, dl, out, 1, 1); }
+int blsbn254_encode_to_g2_batch(blsbn254_ctx* c, const uint8_t* m, const uint64_t* o, size_t n, const uint8_t* d, size_t dl, uint8_t* out) { return h2c_common(c, m, o, n, d, dl, out, 1, 0); }
+
+// ---------------- point checks
+static int check_common(blsbn254_ctx* c, const uint8_t* pts, size_t n, uint8_t* bm, int g2) {
+  if (!c || (n && (!pts || !bm))) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t sz = g2 ? 128 : 64, nb = (n + 7) / 8;
+  HIPCHK(c, c->in_a.reserve(sz * n)); HIPCHK(c, c->bitmap.reserve(nb + 8));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, pts, sz * n, hipMemcpyHostToDevice, c->stream));
+  if (g2) { LAUNCH(c, "g2_check", k_g2_check, n, (const uint8_t*)c->in_a.p, n, (uint8_t*)nullptr, (uint8_t*)c->bitmap.p); }
+  else { LAUNCH(c, "g1_check", k_g1_check, n, (const uint8_t*)c->in_a.p, n, (uint8_t*)c->bitmap.p); }
+  HIPCHK(c, hipMemcpyAsync(bm, c->bitmap.p, nb, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int blsbn254_g1_check_batch(blsbn254_ctx* c, const uint8_t* g1, size_t n, uint8_t* bm) { return check_common(c, g1, n, bm, 0); }
+int blsbn254_g2_check_batch(blsbn254_ctx* c, const uint8_t* g2, size_t n, uint8_t* bm) { return check_common(c, g2, n, bm, 1); }
+
+// ---------------- verify
+int blsbn254_verify_batch_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
+                              const uint8_t* d_sigs, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* d_bitmap) {
+  if (!c || (n && (!d_pks || !d_off || !d_sigs || !d_bitmap)) || (dst_len && !dst)) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
+  if (rc) return rc;
+  HIPCHK(c, c->h_ws.reserve(n * 18 * 4)); HIPCHK(c, c->f_ws.reserve(n * 108 * 4));
+  HIPCHK(c, c->flags.reserve(n)); HIPCHK(c, c->sub_ok.reserve(n));
+  LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, d_msgs, d_off, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, (uint8_t*)nullptr, 0);
+  LAUNCH(c, "g2_check", k_g2_check, n, d_pks, n, (uint8_t*)c->sub_ok.p, (uint8_t*)nullptr);
+  LAUNCH(c, "miller_verify", k_miller_verify, n, d_pks, d_sigs, (const int32_t*)c->h_ws.p, n, (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
+  LAUNCH(c, "final_exp", k_final_exp, n, (const int32_t*)c->f_ws.p, n, n, (const uint8_t*)c->flags.p, (const uint8_t*)c->sub_ok.p, d_bitmap, (uint8_t*)nullptr, 0);
+  return 0;
+}
+int blsbn254_verify_batch(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs,
+                          size_t n, const uint8_t* dst, size_t dst_len, uint8_t* bm) {
+  if (!c || !off || (n && (!pks || !sigs || !bm)) || (dst_len && !dst)) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = stage_msgs(c, msgs, off, n);
+  if (rc) return rc;
+  size_t nb = (n + 7) / 8;
+  HIPCHK(c, c->in_a.reserve(128 * n)); HIPCHK(c, c->in_b.reserve(64 * n)); HIPCHK(c, c->bitmap.reserve(nb + 8));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->in_b.p, sigs, 64 * n, hipMemcpyHostToDevice, c->stream));
+  rc = blsbn254_verify_batch_dev(c, (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p,
+                                 (const uint8_t*)c->in_b.p, n, dst, dst_len, (uint8_t*)c->bitmap.p);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(bm, c->bitmap.p, nb, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int blsbn254_aggregate_verify(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
+                              const uint8_t agg_sig[64], const uint8_t* dst, size_t dst_len, int* valid) {
+  if (!c || !valid || !agg_sig || !off || (n && !pks) || (dst_len && !dst)) return BLSBN254_E_ARG;
+  *valid = 0;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
+  if (rc) return rc;
+  rc = stage_msgs(c, msgs, off, n);
+  if (rc) return rc;
+  size_t m = n + 1;                                   // slot n holds the (agg_sig, -G2gen) pair
+  HIPCHK(c, c->in_a.reserve(128 * n)); HIPCHK(c, c->in_b.reserve(64 + 128));
+  HIPCHK(c, c->h_ws.reserve(n * 18 * 4)); HIPCHK(c, c->f_ws.reserve(m * 108 * 4));
+  HIPCHK(c, c->flags.reserve(n)); HIPCHK(c, c->sub_ok.reserve(n)); HIPCHK(c, c->status.reserve(8)); HIPCHK(c, c->misc.reserve(64)); HIPCHK(c, c->bitmap.reserve(16));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * n, hipMemcpyHostToDevice, c->stream));
+  // -G2gen = (x, p - y) of the generator fp2.rs:305-333
+  static const uint8_t neg_g2[128] = {
+    0x19,0x8e,0x93,0x93,0x92,0x0d,0x48,0x3a,0x72,0x60,0xbf,0xb7,0x31,0xfb,0x5d,0x25,0xf1,0xaa,0x49,0x33,0x35,0xa9,0xe7,0x12,0x97,0xe4,0x85,0xb7,0xae,0xf3,0x12,0xc2,
+    0x18,0x00,0xde,0xef,0x12,0x1f,0x1e,0x76,0x42,0x6a,0x00,0x66,0x5e,0x5c,0x44,0x79,0x67,0x43,0x22,0xd4,0xf7,0x5e,0xda,0xdd,0x46,0xde,0xbd,0x5c,0xd9,0x92,0xf6,0xed,
+    0x27,0x5d,0xc4,0xa2,0x88,0xd1,0xaf,0xb3,0xcb,0xb1,0xac,0x09,0x18,0x75,0x24,0xc7,0xdb,0x36,0x39,0x5d,0xf7,0xbe,0x3b,0x99,0xe6,0x73,0xb1,0x3a,0x07,0x5a,0x65,0xec,
+    0x1d,0x9b,0xef,0xcd,0x05,0xa5,0x32,0x3e,0x6d,0xa4,0xd4,0x35,0xf3,0xb6,0x17,0xcd,0xb3,0xaf,0x83,0x28,0x5c,0x2d,0xf7,0x11,0xef,0x39,0xc0,0x15,0x71,0x82,0x7f,0x9d};
+  uint8_t last[64 + 128];
+  std::memcpy(last, agg_sig, 64); std::memcpy(last + 64, neg_g2, 128);
+  HIPCHK(c, hipMemcpyAsync(c->in_b.p, last, sizeof last, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));         // `last` is on the stack
+  int32_t* f = (int32_t*)c->f_ws.p;
+  LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, (uint8_t*)nullptr, 0);
+  LAUNCH(c, "g2_check", k_g2_check, n, (const uint8_t*)c->in_a.p, n, (uint8_t*)c->sub_ok.p, (uint8_t*)nullptr);
+  LAUNCH(c, "miller_hpk", k_miller_hpk, n, (const int32_t*)c->h_ws.p, (const uint8_t*)c->in_a.p, n, f, m, (uint8_t*)c->flags.p);
+  LAUNCH(c, "miller_1", k_miller_1, 1, (const uint8_t*)c->in_b.p, (const uint8_t*)c->in_b.p + 64, (size_t)1, f + n, m, (uint8_t*)c->status.p);
+  LAUNCH(c, "g1_check", k_g1_check, 1, (const uint8_t*)c->in_b.p, (size_t)1, (uint8_t*)c->bitmap.p);
+  int* d_flags = (int*)c->misc.p;                     // [0] all pks ok, [1] product == 1 after final exp
+  int init[2] = {1, 0};
+  HIPCHK(c, hipMemcpyAsync(d_flags, init, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  LAUNCH(c, "and_reduce", k_and_reduce, n, (const uint8_t*)c->flags.p, (const uint8_t*)c->sub_ok.p, n, d_flags);
+  // product tree over the m Miller values (stride m)
+  HIPCHK(c, c->f_ws2.reserve(((m + 1) / 2) * 108 * 4));
+  int32_t* a = f; int32_t* b = (int32_t*)c->f_ws2.p;
+  size_t sa = m, cnt = m;
+  while (cnt > 1) {
+    size_t mo = (cnt + 1) / 2;
+    LAUNCH(c, "fp12_mul_pairs", k_fp12_mul_pairs, mo, (const int32_t*)a, cnt, sa, b, mo);
+    std::swap(a, b); sa = mo; cnt = mo;
+  }
+  LAUNCH(c, "final_exp_is_one", k_final_exp_is_one, 1, (const int32_t*)a, sa, d_flags + 1);
+  int h_flags[2]; uint8_t sig_st, sig_on_curve;
+  HIPCHK(c, hipMemcpyAsync(h_flags, d_flags, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&sig_st, c->status.p, 1, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&sig_on_curve, c->bitmap.p, 1, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  bool sig_ok = (sig_st & 7) == 3 && (sig_on_curve & 1);      // decodes, not the identity, on the curve
+  *valid = (sig_ok && h_flags[0] == 1 && h_flags[1] == 1) ? 1 : 0;
+  return 0;
+}
+// n G1 points (limb-major projective, stride n) in c->h_ws -> their sum as 64 bytes
+static int g1_sum_to_bytes(blsbn254_ctx* c, size_t n, uint8_t out[64]) {
+  HIPCHK(c, c->f_ws2.reserve(((n + 1) / 2) * 27 * 4)); HIPCHK(c, c->out.reserve(64));
+  int32_t* a = (int32_t*)c->h_ws.p; int32_t* b = (int32_t*)c->f_ws2.p;
+  size_t sa = n, cnt = n;
+  while (cnt > 1) {
+    size_t mo = (cnt + 1) / 2;
+    LAUNCH(c, "g1_add_pairs", k_g1_add_pairs, mo, (const int32_t*)a, cnt, sa, b, mo);
+    std::swap(a, b); sa = mo; cnt = mo;
+  }
+  LAUNCH(c, "g1_to_bytes", k_g1_to_bytes, 1, (const int32_t*)a, sa, (uint8_t*)c->out.p);
+  HIPCHK(c, hipMemcpyAsync(out, c->out.p, 64, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int blsbn254_aggregate_sigs(blsbn254_ctx* c, const uint8_t* sigs, size_t n, uint8_t out[64]) {
+  if (!c || !out || (n && !sigs)) return BLSBN254_E_ARG;
+  if (n == 0) { std::memset(out, 0, 64); out[63] = 1; return 0; }            // empty sum = identity (0, 1)
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->in_a.reserve(64 * n)); HIPCHK(c, c->h_ws.reserve(n * 27 * 4)); HIPCHK(c, c->status.reserve(n));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, sigs, 64 * n, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "g1_load", k_g1_load, n, (const uint8_t*)c->in_a.p, (const uint8_t*)nullptr, n, (int32_t*)c->h_ws.p, (uint8_t*)c->status.p);
+  int bad; int rc = first_bad(c, (const uint8_t*)c->status.p, n, 1, 1, &bad);
+  if (rc) return rc;
+  if (bad >= 0) return BLSBN254_ERR_G1;
+  return g1_sum_to_bytes(c, n, out);
+}
+int blsbn254_threshold_combine(blsbn254_ctx* c, const uint8_t* ids, const uint8_t* partial_sigs, size_t t, uint8_t out_sig[64]) {
+  if (!c || !out_sig || (t && (!ids || !partial_sigs))) return BLSBN254_E_ARG;
+  if (t == 0) { std::memset(out_sig, 0, 64); out_sig[63] = 1; return 0; }
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->in_a.reserve(64 * t)); HIPCHK(c, c->in_b.reserve(32 * t)); HIPCHK(c, c->scalars.reserve(32 * t));
+  HIPCHK(c, c->h_ws.reserve(t * 27 * 4)); HIPCHK(c, c->status.reserve(t));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, partial_sigs, 64 * t, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->in_b.p, ids, 32 * t, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "lagrange", k_lagrange, t, (const uint8_t*)c->in_b.p, t, (uint8_t*)c->scalars.p, (uint8_t*)c->status.p);
+  int bad; int rc = first_bad(c, (const uint8_t*)c->status.p, t, 1, 1, &bad);
+  if (rc) return rc;
+  if (bad >= 0) return BLSBN254_ERR_SCALAR;
+  LAUNCH(c, "g1_load_mul", k_g1_load, t, (const uint8_t*)c->in_a.p, (const uint8_t*)c->scalars.p, t, (int32_t*)c->h_ws.p, (uint8_t*)c->status.p);
+  rc = first_bad(c, (const uint8_t*)c->status.p, t, 1, 1, &bad);
+  if (rc) return rc;
+  if (bad >= 0) return BLSBN254_ERR_G1;
+  return g1_sum_to_bytes(c, t, out_sig);
+}
+
+}  // extern "C"

@@ -1,0 +1,241 @@
+"""ctypes binding of the C ABI (include/blsbn254.h) with the reference crate's operator names.
+
+Mirrors, for the hot path, the interface a user of mikelodder7/bls-bn254 sees:
+pairing / multi_miller_loop / final_exponentiation (pairings.rs:760-857, :50-178),
+G1Projective::hash / encode, G2Projective::hash / encode (g1.rs:910-928, g2.rs:919-936),
+is_on_curve / is_torsion_free (g1.rs:383-391, g2.rs:409-414, :733-736), Sum (g1.rs:561-565), and the
+Bn254Error variants (error.rs:4-10) as exceptions.  Everything runs on the GPU through
+libblsbn254_hip.so; if the library or a gfx950 device is missing the calls raise -- there is no CPU
+path in this package.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_DST = b"BLS_SIG_BN254G1_XMD:SHA-256_SVDW_RO_NUL_"
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_lib = None
+
+
+class Bn254Error(Exception):
+    """Mirror of the reference's error enum (error.rs:4-10) plus device errors (negative codes)."""
+    code = None
+
+    def __init__(self, code, detail=""):
+        self.code = code
+        msg = load_library().blsbn254_strerror(code).decode()
+        super().__init__("%s (code %d)%s" % (msg, code, (": " + detail) if detail else ""))
+
+
+class InvalidScalarBytes(Bn254Error):
+    pass
+
+
+class InvalidG1Bytes(Bn254Error):
+    pass
+
+
+class InvalidG2Bytes(Bn254Error):
+    pass
+
+
+class InvalidGtBytes(Bn254Error):
+    pass
+
+
+_ERR = {1: InvalidScalarBytes, 2: InvalidG1Bytes, 3: InvalidG2Bytes, 4: InvalidGtBytes}
+
+
+def library_path():
+    return os.path.join(HERE, "libblsbn254_hip.so")
+
+
+def load_library():
+    """Loads the HIP extension.  Fails loudly when it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError("HIP extension %s is missing: run `python -m bls_bn254_amd.build` "
+                               "(or __graft_entry__.build()); there is no CPU fallback" % path)
+        lib = ctypes.CDLL(path)
+        lib.blsbn254_strerror.restype = ctypes.c_char_p
+        lib.blsbn254_last_error.restype = ctypes.c_char_p
+        lib.blsbn254_ctx_stream.restype = ctypes.c_void_p
+        _lib = lib
+    return _lib
+
+
+def _inbuf(b, expect=None):
+    if isinstance(b, np.ndarray):
+        a = np.ascontiguousarray(b, dtype=np.uint8).reshape(-1)
+    else:
+        a = np.frombuffer(bytes(b), dtype=np.uint8)
+    if expect is not None and a.size != expect:
+        raise ValueError("expected %d bytes, got %d" % (expect, a.size))
+    if a.size == 0:
+        a = np.zeros(1, dtype=np.uint8)
+    return a, a.ctypes.data_as(_u8p)
+
+
+def _outbuf(n):
+    a = np.zeros(max(n, 1), dtype=np.uint8)
+    return a, a.ctypes.data_as(_u8p)
+
+
+def pack_messages(msgs):
+    """list of bytes -> (concatenated bytes, n+1 uint64 offsets)"""
+    off = np.zeros(len(msgs) + 1, dtype=np.uint64)
+    if msgs:
+        off[1:] = np.cumsum([len(m) for m in msgs], dtype=np.uint64)
+    return b"".join(msgs), off
+
+
+class Engine:
+    """One context = one GPU (blsbn254_ctx): stream, workspace, resident -G2gen line table."""
+
+    def __init__(self, device=0):
+        self._lib = load_library()
+        self._ctx = ctypes.c_void_p()
+        rc = self._lib.blsbn254_ctx_create(ctypes.c_int(device), ctypes.byref(self._ctx))
+        if rc != 0:
+            self._ctx = None
+            raise Bn254Error(rc)
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.blsbn254_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            detail = self._lib.blsbn254_last_error(self._ctx).decode() if rc == -2 else ""
+            raise _ERR.get(rc, Bn254Error)(rc, detail)
+
+    # ---- primitives (reference operator API)
+    def pairing_batch(self, g1, g2, n):
+        a, pa = _inbuf(g1, 64 * n); b, pb = _inbuf(g2, 128 * n); o, po = _outbuf(384 * n)
+        self._chk(self._lib.blsbn254_pairing_batch(self._ctx, pa, pb, ctypes.c_size_t(n), po))
+        return o[:384 * n].tobytes()
+
+    def pairing(self, g1, g2):
+        return self.pairing_batch(g1, g2, 1)
+
+    def miller_loop_batch(self, g1, g2, n):
+        a, pa = _inbuf(g1, 64 * n); b, pb = _inbuf(g2, 128 * n); o, po = _outbuf(384 * n)
+        self._chk(self._lib.blsbn254_miller_loop_batch(self._ctx, pa, pb, ctypes.c_size_t(n), po))
+        return o[:384 * n].tobytes()
+
+    def multi_miller_loop(self, g1, g2, n):
+        a, pa = _inbuf(g1, 64 * n); b, pb = _inbuf(g2, 128 * n); o, po = _outbuf(384)
+        self._chk(self._lib.blsbn254_multi_miller_loop(self._ctx, pa, pb, ctypes.c_size_t(n), po))
+        return o.tobytes()
+
+    def final_exponentiation(self, ml, n=1):
+        a, pa = _inbuf(ml, 384 * n); o, po = _outbuf(384 * n)
+        self._chk(self._lib.blsbn254_final_exponentiation(self._ctx, pa, ctypes.c_size_t(n), po))
+        return o[:384 * n].tobytes()
+
+    def _h2c(self, fn, msgs, dst, size):
+        data, off = pack_messages(msgs)
+        a, pa = _inbuf(data); d, pd = _inbuf(dst); o, po = _outbuf(size * len(msgs))
+        self._chk(fn(self._ctx, pa, off.ctypes.data_as(_u64p), ctypes.c_size_t(len(msgs)), pd, ctypes.c_size_t(len(dst)), po))
+        return o[:size * len(msgs)].tobytes()
+
+    def hash_to_g1_batch(self, msgs, dst): return self._h2c(self._lib.blsbn254_hash_to_g1_batch, msgs, dst, 64)
+    def encode_to_g1_batch(self, msgs, dst): return self._h2c(self._lib.blsbn254_encode_to_g1_batch, msgs, dst, 64)
+    def hash_to_g2_batch(self, msgs, dst): return self._h2c(self._lib.blsbn254_hash_to_g2_batch, msgs, dst, 128)
+    def encode_to_g2_batch(self, msgs, dst): return self._h2c(self._lib.blsbn254_encode_to_g2_batch, msgs, dst, 128)
+
+    def g1_check_batch(self, g1, n):
+        a, pa = _inbuf(g1, 64 * n); o, po = _outbuf((n + 7) // 8)
+        self._chk(self._lib.blsbn254_g1_check_batch(self._ctx, pa, ctypes.c_size_t(n), po))
+        return o[:(n + 7) // 8].tobytes()
+
+    def g2_check_batch(self, g2, n):
+        a, pa = _inbuf(g2, 128 * n); o, po = _outbuf((n + 7) // 8)
+        self._chk(self._lib.blsbn254_g2_check_batch(self._ctx, pa, ctypes.c_size_t(n), po))
+        return o[:(n + 7) // 8].tobytes()
+
+    # ---- BLS layer
+    def verify_batch(self, pks, msgs, sigs, dst=DEFAULT_DST):
+        n = len(msgs)
+        data, off = pack_messages(msgs)
+        a, pa = _inbuf(pks, 128 * n); m, pm = _inbuf(data); s, ps = _inbuf(sigs, 64 * n); d, pd = _inbuf(dst)
+        o, po = _outbuf((n + 7) // 8)
+        self._chk(self._lib.blsbn254_verify_batch(self._ctx, pa, pm, off.ctypes.data_as(_u64p), ps, ctypes.c_size_t(n), pd,
+                                                  ctypes.c_size_t(len(dst)), po))
+        return o[:(n + 7) // 8].tobytes()
+
+    def aggregate_verify(self, pks, msgs, agg_sig, dst=DEFAULT_DST):
+        n = len(msgs)
+        data, off = pack_messages(msgs)
+        a, pa = _inbuf(pks, 128 * n); m, pm = _inbuf(data); s, ps = _inbuf(agg_sig, 64); d, pd = _inbuf(dst)
+        valid = ctypes.c_int(0)
+        self._chk(self._lib.blsbn254_aggregate_verify(self._ctx, pa, pm, off.ctypes.data_as(_u64p), ctypes.c_size_t(n), ps, pd,
+                                                      ctypes.c_size_t(len(dst)), ctypes.byref(valid)))
+        return bool(valid.value)
+
+    def aggregate_sigs(self, sigs, n):
+        a, pa = _inbuf(sigs, 64 * n); o, po = _outbuf(64)
+        self._chk(self._lib.blsbn254_aggregate_sigs(self._ctx, pa, ctypes.c_size_t(n), po))
+        return o.tobytes()
+
+    def threshold_combine(self, ids, partial_sigs, t):
+        a, pa = _inbuf(ids, 32 * t); s, ps = _inbuf(partial_sigs, 64 * t); o, po = _outbuf(64)
+        self._chk(self._lib.blsbn254_threshold_combine(self._ctx, pa, ps, ctypes.c_size_t(t), po))
+        return o.tobytes()
+
+    # ---- device-resident variants (raw device pointers, e.g. torch tensor .data_ptr())
+    def verify_batch_dev(self, d_pks, d_msgs, d_off, d_sigs, n, d_bitmap, dst=DEFAULT_DST):
+        d, pd = _inbuf(dst)
+        self._chk(self._lib.blsbn254_verify_batch_dev(self._ctx, ctypes.c_void_p(d_pks), ctypes.c_void_p(d_msgs), ctypes.c_void_p(d_off),
+                                                      ctypes.c_void_p(d_sigs), ctypes.c_size_t(n), pd, ctypes.c_size_t(len(dst)),
+                                                      ctypes.c_void_p(d_bitmap)))
+
+    def pairing_batch_dev(self, d_g1, d_g2, n, d_gt, d_status=0):
+        self._chk(self._lib.blsbn254_pairing_batch_dev(self._ctx, ctypes.c_void_p(d_g1), ctypes.c_void_p(d_g2), ctypes.c_size_t(n),
+                                                       ctypes.c_void_p(d_gt), ctypes.c_void_p(d_status)))
+
+    def synchronize(self):
+        self._chk(self._lib.blsbn254_ctx_synchronize(self._ctx))
+
+    @property
+    def stream(self):
+        return self._lib.blsbn254_ctx_stream(self._ctx)
+
+    # ---- measurement hooks
+    def profile_enable(self, on=True):
+        self._chk(self._lib.blsbn254_profile_enable(self._ctx, ctypes.c_int(1 if on else 0)))
+
+    def profile_reset(self):
+        self._chk(self._lib.blsbn254_profile_reset(self._ctx))
+
+    def profile_read(self):
+        names = ctypes.create_string_buffer(32 * 64)
+        launches = (ctypes.c_uint64 * 64)()
+        ms = (ctypes.c_double * 64)()
+        k = self._lib.blsbn254_profile_read(self._ctx, names, launches, ms, ctypes.c_int(64))
+        if k < 0:
+            self._chk(k)
+        out = {}
+        for i in range(k):
+            nm = names.raw[32 * i:32 * i + 32].split(b"\0")[0].decode()
+            out[nm] = {"launches": int(launches[i]), "total_ms": float(ms[i])}
+        return out

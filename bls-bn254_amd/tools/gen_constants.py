@@ -236,10 +236,17 @@ def main():
     s.append("BN_CONST uint64_t EXP_PM1_2[4] = %s;     // (p-1)/2\n" % words((P - 1) // 2))
     s.append("BN_CONST uint64_t EXP_PP1_4[4] = %s;     // (p+1)/4\n" % words((P + 1) // 4))
     s.append("BN_CONST uint64_t EXP_PM3_4[4] = %s;     // (p-3)/4\n" % words((P - 3) // 4))
+    # scalar field Fr (threshold path: Lagrange coefficients), same radix / Montgomery radius
+    s.append("BN_CONST int32_t FR_MOD[9] = %s;   // r, plain limbs\n" % fmt_limbs(limbs(RR)))
+    s.append("BN_CONST int32_t FR_PINV = %d;     // -r^-1 mod 2^29\n" % ((-pow(RR, -1, 1 << RB)) % (1 << RB)))
+    s.append("BN_CONST int32_t FR_ONE[9] = %s;   // R mod r\n" % fmt_limbs(limbs(MONT_R % RR)))
+    s.append("BN_CONST int32_t FR_R2[9] = %s;    // R^2 mod r\n" % fmt_limbs(limbs(MONT_R * MONT_R % RR)))
+    s.append("BN_CONST uint64_t EXP_RM2[4] = %s;       // r-2\n" % words(RR - 2))
     s.append("}  // namespace bnc\n\n")
     # fixed-Q line table for -G2gen (the verify equation pairs the signature with -G2gen)
     negG2 = (G2X, f2neg(G2Y))
     tab = line_table(negG2, g1)
+    s.append("#define BN_ATE_NAF_INIT {%s}\n" % ", ".join(str(d) for d in dg))
     s.append("// Line coefficients (c0, c1, c2) of the optimal ate loop for the fixed point Q = -G2gen, in\n")
     s.append("// evaluation order (doubling step, then the addition step if the NAF digit is non-zero, ...,\n")
     s.append("// then the two Frobenius additions).  Each entry: 3 Fp2 = 54 limbs.\n")

@@ -1,0 +1,122 @@
+/* blsbn254.h -- C ABI of the MI355X-native batched BLS-BN254 verification engine.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / HIP types.  Each entry point
+ * names the operator of the reference crate (mikelodder7/bls-bn254, /root/reference) whose body a
+ * Rust shim would replace with the extern "C" call (INTEGRATION.md shows the binding).  The
+ * reference has no FFI and no BLS scheme layer; the verify / aggregate /
+ * threshold entry points are the IETF CoreVerify / CoreAggregateVerify composition of its
+ * primitives, min-sig variant (signatures in G1, public keys in G2).
+ *
+ * Byte formats (authoritative, big-endian field elements):
+ *   G1  64 B  x || y                          G1Affine::to_uncompressed      g1.rs:297-302
+ *   G2 128 B  x.c1 || x.c0 || y.c1 || y.c0    G2Affine::to_uncompressed      g2.rs:292-300
+ *   Gt 384 B  c0.c0.c0, c0.c0.c1, c0.c1.c0 .. c1.c2.c1   Gt::to_repr         pairings.rs:499-514
+ *   Fr  32 B  big-endian (both directions; the reference's LE to_repr, E11, is not reproduced)
+ *   identity: G1 = (0, 1), G2 = (0, 1); on input x == 0 means identity (g1.rs:352-353, g2.rs:377)
+ *   Decoding is strict: a coordinate >= p is an error (the reference masks bit 255 of G1
+ *   coordinates, g1.rs:346-347; not reproduced).  Compressed encodings are not accepted (the
+ *   reference's G1 compressed codec is defective).
+ *   msgs = concatenated message bytes, off = n+1 offsets (off[i]..off[i+1] is message i).
+ *   bitmaps: ceil(n/8) bytes, bit i of the batch = bit (i & 7) of byte i >> 3.
+ *
+ * Return codes: 0 ok; 1..4 = Bn254Error::{InvalidScalarBytes, InvalidG1Bytes, InvalidG2Bytes,
+ * InvalidGtBytes} in declaration order (error.rs:4-10), returned by the primitive entry points
+ * when an operand does not decode (as the reference's TryFrom<&[u8]> does, macros.rs:130-136);
+ * negative = BLSBN254_E_*.  In verify_batch a tuple that fails to decode or validate is NOT an
+ * error: its bit in the output bitmap is cleared.
+ *
+ * Threading: a ctx owns one HIP stream and its device workspace on one GPU; calls on one ctx must
+ * be externally serialized (the reference is pure and single-threaded, inner_types.rs:33-34).
+ * The library never retains caller pointers past return.  There is NO CPU fallback: every entry
+ * point fails with BLSBN254_E_NO_DEVICE when no gfx950 device is available.
+ */
+#ifndef BLSBN254_H
+#define BLSBN254_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct blsbn254_ctx blsbn254_ctx;
+
+#define BLSBN254_OK 0
+#define BLSBN254_ERR_SCALAR 1 /* Bn254Error::InvalidScalarBytes */
+#define BLSBN254_ERR_G1 2     /* Bn254Error::InvalidG1Bytes */
+#define BLSBN254_ERR_G2 3     /* Bn254Error::InvalidG2Bytes */
+#define BLSBN254_ERR_GT 4     /* Bn254Error::InvalidGtBytes */
+#define BLSBN254_E_ARG (-1)
+#define BLSBN254_E_HIP (-2)
+#define BLSBN254_E_NOMEM (-3)
+#define BLSBN254_E_NO_DEVICE (-4)
+
+/* One context per GPU (device = HIP ordinal).  Replaces nothing in the reference (it has no
+ * state); owns the stream, the workspace and the resident -G2gen line table. */
+int blsbn254_ctx_create(int device, blsbn254_ctx** out);
+void blsbn254_ctx_destroy(blsbn254_ctx* ctx);
+const char* blsbn254_strerror(int code);
+const char* blsbn254_last_error(blsbn254_ctx* ctx); /* text of the last HIP error on this ctx */
+
+/* ---- primitives, 1:1 with the reference operator API ------------------------------------- */
+/* pairing(&G1Affine, &G2Affine) -> Gt, pairings.rs:760-802 (pairing::Engine::pairing :685-696).
+ * Identity in either slot gives Gt::IDENTITY. */
+int blsbn254_pairing_batch(blsbn254_ctx* ctx, const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t* gt);
+/* multi_miller_loop(&[(&G1Affine, &G2Prepared)]) -> MillerLoopResult, pairings.rs:808-857
+ * (pairing::MultiMillerLoop :706-713).  Pairs with an identity member are skipped.  Output = the
+ * 384-byte Fp12 Miller-loop value (before final exponentiation). */
+int blsbn254_multi_miller_loop(blsbn254_ctx* ctx, const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t ml_out[384]);
+/* per-pair Miller loops (no product): n outputs of 384 B */
+int blsbn254_miller_loop_batch(blsbn254_ctx* ctx, const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t* ml_out);
+/* MillerLoopResult::final_exponentiation, pairings.rs:50-178 (pairing::MillerLoopResult :698-704) */
+int blsbn254_final_exponentiation(blsbn254_ctx* ctx, const uint8_t* ml, size_t n, uint8_t* gt);
+/* G1Projective::hash::<ExpandMsgXmd<Sha256>>(msg, dst), g1.rs:910-919; ::encode g1.rs:922-928 */
+int blsbn254_hash_to_g1_batch(blsbn254_ctx* ctx, const uint8_t* msgs, const uint64_t* off, size_t n,
+                              const uint8_t* dst, size_t dst_len, uint8_t* out);
+int blsbn254_encode_to_g1_batch(blsbn254_ctx* ctx, const uint8_t* msgs, const uint64_t* off, size_t n,
+                                const uint8_t* dst, size_t dst_len, uint8_t* out);
+/* G2Projective::hash / ::encode, g2.rs:919-936 */
+int blsbn254_hash_to_g2_batch(blsbn254_ctx* ctx, const uint8_t* msgs, const uint64_t* off, size_t n,
+                              const uint8_t* dst, size_t dst_len, uint8_t* out);
+int blsbn254_encode_to_g2_batch(blsbn254_ctx* ctx, const uint8_t* msgs, const uint64_t* off, size_t n,
+                                const uint8_t* dst, size_t dst_len, uint8_t* out);
+/* G1Affine::from_uncompressed + is_on_curve (g1.rs:339-360, :383-391); G1 has cofactor 1 */
+int blsbn254_g1_check_batch(blsbn254_ctx* ctx, const uint8_t* g1, size_t n, uint8_t* ok_bitmap);
+/* G2Affine::from_uncompressed + is_on_curve + is_torsion_free (g2.rs:350-414, :733-736) */
+int blsbn254_g2_check_batch(blsbn254_ctx* ctx, const uint8_t* g2, size_t n, uint8_t* ok_bitmap);
+
+/* ---- BLS layer (build-defined composition; min-sig) ---------------------------------------- */
+/* valid_i = sig_i in G1 \ {O}  and  pk_i in G2 \ {O} (on curve, torsion free)  and
+ *           e(sig_i, -G2gen) * e(H(msg_i), pk_i) == 1 */
+int blsbn254_verify_batch(blsbn254_ctx* ctx, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off,
+                          const uint8_t* sigs, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* valid_bitmap);
+/* valid = prod_i e(H(msg_i), pk_i) * e(agg_sig, -G2gen) == 1, every pk_i valid, n >= 1 */
+int blsbn254_aggregate_verify(blsbn254_ctx* ctx, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
+                              const uint8_t agg_sig[64], const uint8_t* dst, size_t dst_len, int* valid);
+/* impl Sum for G1Projective, g1.rs:561-565 */
+int blsbn254_aggregate_sigs(blsbn254_ctx* ctx, const uint8_t* sigs, size_t n, uint8_t out[64]);
+/* sum_i lambda_i * sig_i with Lagrange coefficients at 0 for the t distinct non-zero ids
+ * (Mul<Scalar> g1.rs:518-534 + Sum; Fr arithmetic scalar.rs:523-548) */
+int blsbn254_threshold_combine(blsbn254_ctx* ctx, const uint8_t* ids, const uint8_t* partial_sigs, size_t t, uint8_t out_sig[64]);
+
+/* ---- device-resident variants (plumbing for callers that already hold the batch in HBM) ----- */
+/* All d_* pointers are device pointers on ctx's GPU.  Work is enqueued on ctx's stream and is
+ * complete after blsbn254_ctx_synchronize().  d_valid_bitmap needs ceil(n/8) bytes. */
+int blsbn254_verify_batch_dev(blsbn254_ctx* ctx, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
+                              const uint8_t* d_sigs, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* d_valid_bitmap);
+int blsbn254_pairing_batch_dev(blsbn254_ctx* ctx, const uint8_t* d_g1, const uint8_t* d_g2, size_t n, uint8_t* d_gt,
+                               uint8_t* d_status /* n bytes or NULL */);
+int blsbn254_ctx_synchronize(blsbn254_ctx* ctx);
+void* blsbn254_ctx_stream(blsbn254_ctx* ctx); /* the hipStream_t */
+
+/* ---- measurement hooks (bench.py) ------------------------------------------------------------ */
+/* When enabled, every kernel launch on the ctx is bracketed by HIP events on the ctx stream;
+ * profile_read returns, per kernel name, the number of launches and the summed duration in ms
+ * since the last reset (it synchronizes the stream). */
+int blsbn254_profile_enable(blsbn254_ctx* ctx, int on);
+int blsbn254_profile_reset(blsbn254_ctx* ctx);
+int blsbn254_profile_read(blsbn254_ctx* ctx, char* names /* max_entries*32 */, uint64_t* launches, double* total_ms, int max_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

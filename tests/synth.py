@@ -1,0 +1,76 @@
+"""Deterministic synthetic BLS batches: seeded key pool, 32-byte messages, signatures
+made with the CPU oracle, and a known pattern of invalid tuples.  Test/bench data generation only."""
+import hashlib
+
+import numpy as np
+
+SEED = b"BLSBN254"
+R = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
+P = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
+
+
+def sk_of(k):
+    h = hashlib.sha256(SEED + b"sk" + k.to_bytes(4, "little")).digest() + hashlib.sha256(SEED + b"sk" + k.to_bytes(4, "little") + b"\x01").digest()
+    return int.from_bytes(h[:48], "big") % R or 1
+
+
+def msg_of(i):
+    return hashlib.sha256(SEED + b"msg" + i.to_bytes(8, "little")).digest()
+
+
+def make_batch(oracle, n, dst, pool=8, invalid_every=0, uniq=None):
+    """Returns (pks bytes, msgs list, sigs bytes, expected bool list).  `uniq` distinct signed tuples are
+    generated with the oracle and tiled to n (signing is CPU-bound); every `invalid_every`-th tuple is
+    corrupted in a rotating way."""
+    uniq = min(n, uniq or n)
+    sks = [sk_of(k) for k in range(pool)]
+    pk_pool = [oracle.sk_to_pk(s) for s in sks]
+    base = []
+    for i in range(uniq):
+        m = msg_of(i)
+        base.append((pk_pool[i % pool], m, oracle.sign(sks[i % pool], m, dst)))
+    g1 = oracle.g1_generator()
+    pks, msgs, sigs, exp = [], [], [], []
+    for i in range(n):
+        pk, m, s = base[i % uniq]
+        ok = True
+        if invalid_every and i % invalid_every == invalid_every - 1:
+            kind = (i // invalid_every) % 5
+            ok = False
+            if kind == 0:
+                m = bytes([m[0] ^ 1]) + m[1:]                         # flipped message bit
+            elif kind == 1:
+                s = oracle.g1_add(s, g1)                              # wrong signature (still on curve)
+            elif kind == 2:
+                pk = pk_pool[(i % uniq + 1) % pool]                   # wrong key
+            elif kind == 3:
+                s = s[:32] + (int.from_bytes(s[32:], "big") ^ 1).to_bytes(32, "big")   # off-curve signature
+            else:
+                pk = NON_SUBGROUP_PK                                  # on the twist, not in the r-torsion
+        pks.append(pk); msgs.append(m); sigs.append(s); exp.append(ok)
+    return b"".join(pks), msgs, b"".join(sigs), exp
+
+
+def bitmap_of(bools):
+    a = np.packbits(np.array(bools, dtype=np.uint8), bitorder="little")
+    return a.tobytes()
+
+
+# a point of E'(Fp2) outside the r-torsion (found with the pure-Python model, seed 11); x.c1|x.c0|y.c1|y.c0
+NON_SUBGROUP_PK = None
+
+
+def _init_non_subgroup():
+    global NON_SUBGROUP_PK
+    from oracle.pyref import bn254 as B
+    import random
+    rnd = random.Random(11)
+    while True:
+        x = (rnd.randrange(P), rnd.randrange(P))
+        y = B.f2_sqrt(B.f2_add(B.f2_mul(B.f2_sqr(x), x), B.B2))
+        if y is not None:
+            NON_SUBGROUP_PK = B.g2_to_bytes((x, y))
+            return
+
+
+_init_non_subgroup()
