@@ -187,6 +187,25 @@ BN_KERNEL k_lagrange(const uint8_t* ids, size_t t, uint8_t* scalars, uint8_t* st
   fr_to_be(scalars + 32 * i, lam);
   status[i] = ok ? 1 : 0;
 }
+// VALU roofline probe: independent v_mad_u64_u32 chains, every CU busy (the denominator of
+// bench.py's roofline.frac is measured in the same run, BASELINE.md section 3 "same-run rule")
+__global__ void __launch_bounds__(256) k_valu_peak(uint32_t* out, uint32_t seed, int iters) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t a = seed * 2654435761u + tid, b = (seed ^ 0x9e3779b9u) + tid * 7u;
+  uint64_t acc[8];
+  for (int c = 0; c < 8; ++c) acc[c] = tid + c;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      uint64_t r;
+      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc[c]) : "vcc");
+      acc[c] = r;
+    }
+  }
+  uint64_t s = 0;
+  for (int c = 0; c < 8; ++c) s ^= acc[c];
+  out[tid] = (uint32_t)s ^ (uint32_t)(s >> 32);
+}
 // status reductions
 __global__ void k_status_reduce(const uint8_t* status, size_t n, uint8_t want_mask, uint8_t want_val, int* first_bad) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -307,6 +326,31 @@ int blsbn254_profile_read(blsbn254_ctx* c, char* names, uint64_t* launches, doub
     if (k < max_entries) { std::snprintf(names + 32 * k, 32, "%s", kv.first.c_str()); launches[k] = p.launches; total_ms[k] = p.ms; ++k; }
   }
   return k;
+}
+
+// Measured v_mad_u64_u32 issue rate of the whole chip (lane-MADs per second), 4 waves per SIMD.
+int blsbn254_valu_peak(blsbn254_ctx* c, double* mads_per_s) {
+  if (!c || !mads_per_s) return BLSBN254_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  hipDeviceProp_t prop;
+  HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
+  int blocks = prop.multiProcessorCount * 4, iters = 1 << 16;
+  HIPCHK(c, c->misc.reserve((size_t)blocks * 256 * 4 + 64));
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+  double best = 0;
+  for (int rep = 0; rep < 4; ++rep) {
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    hipLaunchKernelGGL(k_valu_peak, dim3(blocks), dim3(256), 0, c->stream, (uint32_t*)c->misc.p, 1u + rep, iters);
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+    double rate = (double)blocks * 256 * iters * 8 / (ms * 1e-3);
+    if (rep > 0 && rate > best) best = rate;           // rep 0 warms the clocks
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  *mads_per_s = best;
+  return 0;
 }
 
 // DST handling: RFC 9380 5.3.3 (oversize DSTs are pre-hashed); staged into device memory once per call

@@ -61,6 +61,13 @@ def load_library():
         if not os.path.exists(path):
             raise RuntimeError("HIP extension %s is missing: run `python -m bls_bn254_amd.build` "
                                "(or __graft_entry__.build()); there is no CPU fallback" % path)
+        # torch ships its own HIP runtime with the same SONAME as /opt/rocm's: whichever is loaded first
+        # serves the whole process, and torch only finds its GPUs through its own copy.  Load torch's
+        # first when it is installed so that the extension and torch share one runtime (plumbing only).
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         lib = ctypes.CDLL(path)
         lib.blsbn254_strerror.restype = ctypes.c_char_p
         lib.blsbn254_last_error.restype = ctypes.c_char_p
@@ -226,6 +233,12 @@ class Engine:
 
     def profile_reset(self):
         self._chk(self._lib.blsbn254_profile_reset(self._ctx))
+
+    def valu_peak(self):
+        """Measured whole-chip v_mad_u64_u32 rate (lane-MADs/s)."""
+        v = ctypes.c_double(0)
+        self._chk(self._lib.blsbn254_valu_peak(self._ctx, ctypes.byref(v)))
+        return v.value
 
     def profile_read(self):
         names = ctypes.create_string_buffer(32 * 64)

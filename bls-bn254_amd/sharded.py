@@ -1,0 +1,54 @@
+"""Sharding of a verify batch over one-process-per-GPU ranks (torch.distributed; backend "nccl" is
+RCCL over xGMI on MI355X, "gloo" in the CPU tests).
+
+Every (pk, msg, sig) tuple is independent (mirrors the per-term independence of multi_miller_loop,
+pairings.rs:819-824), so rank g verifies the contiguous range [g*n/G, (g+1)*n/G) with no data-path
+collective.  The only exchange is the validity bitmap: each rank places its bits into a zeroed
+full-length int32 word array and the arrays are summed (RCCL has no bitwise OR; the bit sets are
+disjoint, so SUM == OR and no carry can occur).  1 MiB at n = 8M: latency-bound, not link-bound.
+"""
+import numpy as np
+
+
+def shard_range(n, rank, world):
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+def bitmap_bytes_to_bits(bm, m, torch):
+    """uint8 LSB-first bitmap tensor -> 0/1 uint8 tensor of length m (on bm's device)."""
+    shifts = torch.arange(8, device=bm.device, dtype=torch.uint8)
+    return ((bm[:, None] >> shifts[None, :]) & 1).reshape(-1)[:m]
+
+
+def bits_to_words(bits, torch):
+    """0/1 tensor (length multiple of 32) -> int32 words, bit i of the batch = bit (i & 31) of word i >> 5."""
+    w = (bits.reshape(-1, 32).to(torch.int64) << torch.arange(32, device=bits.device, dtype=torch.int64)[None, :]).sum(dim=1)
+    return w.to(torch.int32)       # wraps the sign bit, fine for a bit container
+
+
+def words_to_bitmap_bytes(words, n):
+    """int32 words (host numpy) -> ceil(n/8) bytes LSB-first."""
+    b = np.ascontiguousarray(words).view(np.uint8)
+    return b[:(n + 7) // 8].tobytes()
+
+
+def allreduce_bitmap(local_bm, lo, m, n, dist, torch, group=None):
+    """local_bm: uint8 tensor, LSB-first bitmap of this rank's m tuples (global indices lo..lo+m).
+    Returns the full-batch bitmap as an int32 word tensor, identical on every rank."""
+    nwords = (n + 31) // 32
+    bits = torch.zeros(nwords * 32, dtype=torch.uint8, device=local_bm.device)
+    if m:
+        bits[lo:lo + m] = bitmap_bytes_to_bits(local_bm, m, torch)
+    words = bits_to_words(bits, torch)
+    if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(words, op=dist.ReduceOp.SUM, group=group)
+    return words
+
+
+def verify_batch_sharded(verify_local, n, rank, world, dist, torch, device, group=None):
+    """verify_local(lo, hi) -> uint8 bitmap tensor (on `device`) for global tuples lo..hi.
+    Returns (full bitmap int32 words on `device`, all_valid flag)."""
+    lo, hi = shard_range(n, rank, world)
+    local = verify_local(lo, hi) if hi > lo else torch.zeros(0, dtype=torch.uint8, device=device)
+    words = allreduce_bitmap(local, lo, hi - lo, n, dist, torch, group)
+    return words

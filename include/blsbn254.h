@@ -116,6 +116,9 @@ int blsbn254_profile_enable(blsbn254_ctx* ctx, int on);
 int blsbn254_profile_reset(blsbn254_ctx* ctx);
 int blsbn254_profile_read(blsbn254_ctx* ctx, char* names /* max_entries*32 */, uint64_t* launches, double* total_ms, int max_entries);
 
+/* Measured whole-chip v_mad_u64_u32 issue rate (lane-MADs per second): the VALU roofline denominator. */
+int blsbn254_valu_peak(blsbn254_ctx* ctx, double* mads_per_s);
+
 #ifdef __cplusplus
 }
 #endif

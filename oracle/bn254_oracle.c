@@ -1067,6 +1067,31 @@ int oracle_sign(const uint8_t sk_be[32], const uint8_t* msg, size_t msg_len, con
   g1_encode(sig, g1_to_affine(g1_mul_limbs(g1_from_affine(h), k)));
   return 0;
 }
+/* Exact Fp multiplication counts (mul + sqr) of the algorithmic unit "one BLS verify" of SURVEY.md 8d:
+   out[0] = one-pair Miller loop with a variable Q (incl. the shared f^2), out[1] = the fixed-Q pair when its
+   line coefficients are precomputed (one ell() per table entry, no point arithmetic), out[2] = final
+   exponentiation, out[3] = number of table entries. */
+void oracle_verify_core_counts(uint64_t out[4]) {
+  init();
+  g1a p = {fp_from_u64(1), fp_from_u64(2), 0};
+  g2a q = G2_GEN;
+  u64 m, s;
+  oracle_counters_reset();
+  fp12 f = multi_miller_loop(&p, &q, 1);
+  oracle_counters_get(&m, &s); out[0] = m + s;
+  int lines = 0;
+  for (int j = ATE_NAF_LEN - 2; j >= 0; --j) lines += 1 + (ATE_NAF[j] != 0);
+  lines += 2;
+  oracle_counters_reset();
+  fp12 g = f;
+  for (int i = 0; i < lines; ++i) g = ell(g, q.x, q.y, q.x, p);
+  oracle_counters_get(&m, &s); out[1] = m + s;
+  oracle_counters_reset();
+  g = final_exponentiation(f12_mul(f, g));
+  oracle_counters_get(&m, &s); out[2] = m + s - 54;   /* minus the f*g product above (18 Fp2 mul) */
+  out[3] = (u64)lines;
+  (void)g;
+}
 int oracle_gt_mul(const uint8_t a[384], const uint8_t b[384], uint8_t out[384]) {
   init();
   fp12 x, y;

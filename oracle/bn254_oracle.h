@@ -68,6 +68,7 @@ int oracle_fr_lagrange_at_zero(const uint8_t* ids, size_t t, uint8_t* out /* t*3
 void oracle_sha256(const uint8_t* msg, size_t len, uint8_t out[32]);
 
 /* instrumentation: exact Fp multiplication / squaring counts of the calling thread */
+void oracle_verify_core_counts(uint64_t out[4]);
 void oracle_counters_reset(void);
 void oracle_counters_get(uint64_t* fp_mul, uint64_t* fp_sqr);
 

@@ -227,3 +227,10 @@ def counters_get():
     a = ctypes.c_uint64(0); b = ctypes.c_uint64(0)
     lib().oracle_counters_get(ctypes.byref(a), ctypes.byref(b))
     return a.value, b.value
+
+
+def verify_core_counts():
+    """Exact Fp mul+sqr counts of the algorithmic unit: (variable-Q Miller pair, fixed-Q pair from table, final exp, table entries)."""
+    a = (ctypes.c_uint64 * 4)()
+    lib().oracle_verify_core_counts(a)
+    return tuple(int(v) for v in a)

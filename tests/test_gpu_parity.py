@@ -1,0 +1,228 @@
+"""GPU parity tests (MI355X): every C-ABI entry point of include/blsbn254.h, called through the
+ctypes binding, against the CPU oracle on the same seeded inputs and against the reference's golden
+vectors.  Bit-exact (integer/byte work)."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+H = lambda s: int(s, 16)
+ONE_GT = (1).to_bytes(32, "big") + bytes(352)
+IDENT1 = bytes(32) + (1).to_bytes(32, "big")
+IDENT2 = bytes(64) + bytes(31) + b"\x01" + bytes(32)
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import blsbn254_loader
+    M = blsbn254_loader.load()
+    e = M.Engine(0)           # raises when the HIP extension or the GPU is missing: no fallback
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def M():
+    import blsbn254_loader
+    return blsbn254_loader.load()
+
+
+def test_pairing_golden(eng, oracle, kats):
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    assert eng.pairing_batch(G1, G2, 1).hex() == kats["constants"]["gt_generator_bytes_hex"]   # pairings.rs:971-976
+
+
+def test_pairing_batch_vs_oracle(eng, oracle, pyref):
+    rnd = random.Random(1)
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    n = 70
+    g1 = b"".join(oracle.g1_mul(G1, rnd.randrange(1, pyref.R)) for _ in range(n))
+    g2 = b"".join(oracle.g2_mul(G2, rnd.randrange(1, pyref.R)) for _ in range(n))
+    # identity handling (pairings.rs:789-800): slots 3 and 5
+    g1 = g1[:64 * 3] + IDENT1 + g1[64 * 4:]
+    g2 = g2[:128 * 5] + IDENT2 + g2[128 * 6:]
+    got = eng.pairing_batch(g1, g2, n)
+    assert got == oracle.pairing_batch(g1, g2, n)
+    assert got[384 * 3:384 * 4] == ONE_GT and got[384 * 5:384 * 6] == ONE_GT
+    assert eng.miller_loop_batch(g1, g2, n) == oracle.miller_loop_batch(g1, g2, n)        # bit-exact Miller values
+    ml = eng.multi_miller_loop(g1, g2, n)
+    assert ml == oracle.multi_miller_loop(g1, g2, n)
+    assert eng.final_exponentiation(ml, 1) == oracle.final_exponentiation(ml, 1)
+    assert eng.multi_miller_loop(b"", b"", 0) == ONE_GT
+
+
+def test_bilinearity_on_gpu(eng, oracle, pyref):
+    rnd = random.Random(2)
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    a, b = rnd.randrange(1, pyref.R), rnd.randrange(1, pyref.R)
+    lhs = eng.pairing_batch(oracle.g1_mul(G1, a), oracle.g2_mul(G2, b), 1)
+    assert lhs == oracle.gt_pow(eng.pairing_batch(G1, G2, 1), a * b % pyref.R)
+    assert oracle.gt_pow(lhs, pyref.R) == ONE_GT
+
+
+def test_error_codes(eng, oracle, pyref, M):
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    bad1 = pyref.P.to_bytes(32, "big") + G1[32:]
+    with pytest.raises(M.InvalidG1Bytes):
+        eng.pairing_batch(G1 + bad1, G2 + G2, 2)
+    with pytest.raises(M.InvalidG2Bytes):
+        eng.pairing_batch(G1, pyref.P.to_bytes(32, "big") + G2[32:], 1)
+    with pytest.raises(M.InvalidGtBytes):
+        eng.final_exponentiation(pyref.P.to_bytes(32, "big") + bytes(352), 1)
+    with pytest.raises(M.InvalidG1Bytes):
+        eng.aggregate_sigs(G1 + bad1, 2)
+
+
+def test_hash_to_curve_kats(eng, kats):
+    g1, g2 = kats["g1"], kats["g2"]
+    out = eng.hash_to_g1_batch([v["msg"].encode() for v in g1["hash"]], g1["hash_dst"].encode())
+    for i, v in enumerate(g1["hash"]):
+        assert out[64 * i:64 * i + 64].hex() == v["p_x"] + v["p_y"]                        # g1.rs:1052-1141
+    out = eng.encode_to_g1_batch([v["msg"].encode() for v in g1["encode"]], g1["encode_dst"].encode())
+    for i, v in enumerate(g1["encode"]):
+        assert out[64 * i:64 * i + 64].hex() == v["p_x"] + v["p_y"]                        # g1.rs:981-1049
+    for name, fn in (("hash", eng.hash_to_g2_batch), ("encode", eng.encode_to_g2_batch)):
+        out = fn([v["msg"].encode() for v in g2[name]], g2[name + "_dst"].encode())
+        for i, v in enumerate(g2[name]):
+            assert out[128 * i:128 * i + 128].hex() == v["x_c1"] + v["x_c0"] + v["y_c1"] + v["y_c0"]   # g2.rs:1039-1313
+
+
+def test_hash_to_curve_ragged(eng, oracle):
+    rnd = random.Random(3)
+    msgs = [b"", b"a", bytes(55), bytes(56), bytes(63), bytes(64), bytes(65), os.urandom(119), os.urandom(120), os.urandom(300)]
+    msgs += [bytes(rnd.randrange(256) for _ in range(rnd.randrange(0, 90))) for _ in range(60)]
+    for dst in (b"QUUX-V01-CS02-with-BN254G1_XMD:SHA-256_SVDW_RO_", b"d", b"x" * 255, b"y" * 300):
+        assert eng.hash_to_g1_batch(msgs, dst) == oracle.hash_to_g1_batch(msgs, dst)
+    dst = b"QUUX-V01-CS02-with-BN254G2_XMD:SHA-256_SVDW_RO_"
+    assert eng.hash_to_g2_batch(msgs[:20], dst) == oracle.hash_to_g2_batch(msgs[:20], dst)
+    assert eng.hash_to_g1_batch([], dst) == b""
+
+
+def test_point_checks(eng, oracle, pyref, kats):
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    bp = kats["g2"]["bad_point"]
+    bad = bytes.fromhex(bp["x_c1"] + bp["x_c0"] + bp["y_c1"] + bp["y_c0"])                  # g2.rs:994-1017
+    rnd = random.Random(4)
+    pts2 = [bad, G2, IDENT2, synth.NON_SUBGROUP_PK, pyref.P.to_bytes(32, "big") + G2[32:]]
+    pts2 += [oracle.g2_mul(G2, rnd.randrange(1, pyref.R)) for _ in range(68)]
+    buf = b"".join(pts2)
+    want = oracle.g2_check_batch(buf, len(pts2))
+    assert want[0] & 0x1f == 0b00110
+    assert eng.g2_check_batch(buf, len(pts2)) == want == oracle.g2_check_batch_slow(buf, len(pts2))
+    pts1 = [G1, IDENT1, G1[:32] + (3).to_bytes(32, "big"), pyref.P.to_bytes(32, "big") + G1[32:], G1[:32] + pyref.P.to_bytes(32, "big")]
+    pts1 += [oracle.g1_mul(G1, rnd.randrange(1, pyref.R)) for _ in range(70)]
+    buf = b"".join(pts1)
+    assert eng.g1_check_batch(buf, len(pts1)) == oracle.g1_check_batch(buf, len(pts1))
+    assert oracle.g1_check_batch(buf, len(pts1))[0] & 0x1f == 0b00011
+
+
+@pytest.mark.parametrize("n,invalid_every", [(1, 0), (63, 4), (64, 0), (65, 5), (1000, 8)])
+def test_verify_batch(eng, oracle, M, n, invalid_every):
+    dst = M.DEFAULT_DST
+    pks, msgs, sigs, exp = synth.make_batch(oracle, n, dst, invalid_every=invalid_every, uniq=40)
+    got = eng.verify_batch(pks, msgs, sigs, dst)
+    assert got == synth.bitmap_of(exp)
+    if n <= 65:
+        assert got == oracle.verify_batch(pks, msgs, sigs, dst)
+
+
+def test_verify_negative_cases(eng, oracle, M):
+    dst = M.DEFAULT_DST
+    sks = [synth.sk_of(k) for k in range(2)]
+    pks = [oracle.sk_to_pk(s) for s in sks]
+    msgs = [b"m0", bytes(range(200))]
+    sigs = [oracle.sign(s, m, dst) for s, m in zip(sks, msgs)]
+    G1 = oracle.g1_generator()
+    cases = [
+        (pks[0], b"x", sigs[0]), (pks[1], msgs[0], sigs[0]), (pks[0], msgs[0], oracle.g1_add(sigs[0], G1)),
+        (pks[0], msgs[0], sigs[0][:32] + (5).to_bytes(32, "big")), (pks[0], msgs[0], IDENT1), (IDENT2, msgs[0], sigs[0]),
+        (synth.NON_SUBGROUP_PK, msgs[0], sigs[0]), (b"\xff" * 128, msgs[0], sigs[0]), (pks[0], msgs[0], b"\xff" * 64),
+        (pks[0], msgs[0], sigs[0]), (pks[1], msgs[1], sigs[1]),
+    ]
+    pk_b = b"".join(c[0] for c in cases); ms = [c[1] for c in cases]; sg = b"".join(c[2] for c in cases)
+    got = eng.verify_batch(pk_b, ms, sg, dst)
+    assert got == oracle.verify_batch(pk_b, ms, sg, dst) == bytes([0, 0b110])
+    assert eng.verify_batch(b"", [], b"", dst) == b""
+    # a different ciphersuite tag changes H(msg): valid tuples become invalid
+    assert eng.verify_batch(pks[0], [msgs[0]], sigs[0], b"OTHER_DST") == b"\x00"
+
+
+def test_aggregate(eng, oracle, M):
+    dst = M.DEFAULT_DST
+    n = 37
+    sks = [synth.sk_of(k) for k in range(n)]
+    pks = b"".join(oracle.sk_to_pk(s) for s in sks)
+    msgs = [synth.msg_of(i) for i in range(n)]
+    sigs = b"".join(oracle.sign(s, m, dst) for s, m in zip(sks, msgs))
+    agg = eng.aggregate_sigs(sigs, n)
+    assert agg == oracle.aggregate_sigs(sigs, n)                                          # impl Sum, g1.rs:561-565
+    assert eng.aggregate_sigs(b"", 0) == IDENT1
+    assert eng.aggregate_verify(pks, msgs, agg, dst) is True
+    bad = list(msgs); bad[17] = b"tampered"
+    assert eng.aggregate_verify(pks, bad, agg, dst) is False
+    assert eng.aggregate_verify(pks[:128] + synth.NON_SUBGROUP_PK + pks[256:], msgs, agg, dst) is False
+    assert eng.aggregate_verify(pks, msgs, IDENT1, dst) is False
+    assert eng.aggregate_verify(b"", [], agg, dst) is False
+    assert oracle.aggregate_verify(pks, msgs, agg, dst) and not oracle.aggregate_verify(pks, bad, agg, dst)
+
+
+def test_threshold(eng, oracle, pyref, M):
+    dst = M.DEFAULT_DST
+    rnd = random.Random(9)
+    t, total = 20, 40
+    coeffs = [rnd.randrange(1, pyref.R) for _ in range(t)]
+    f = lambda x: sum(c * pow(x, i, pyref.R) for i, c in enumerate(coeffs)) % pyref.R
+    ids = rnd.sample(range(1, total + 1), t)
+    msg = b"threshold message"
+    h = oracle.hash_to_g1_batch([msg], dst)
+    parts = b"".join(oracle.g1_mul(h, f(i)) for i in ids)
+    idb = b"".join(i.to_bytes(32, "big") for i in ids)
+    sig = eng.threshold_combine(idb, parts, t)
+    assert sig == oracle.threshold_combine(idb, parts, t) == oracle.sign(coeffs[0], msg, dst)
+    assert eng.verify_batch(oracle.sk_to_pk(coeffs[0]), [msg], sig, dst) == b"\x01"
+    with pytest.raises(M.InvalidScalarBytes):
+        eng.threshold_combine(idb[:32] + idb[:32] + idb[64:], parts, t)                   # duplicate id
+    with pytest.raises(M.InvalidScalarBytes):
+        eng.threshold_combine(pyref.R.to_bytes(32, "big") + idb[32:], parts, t)           # id >= r
+    with pytest.raises(M.InvalidScalarBytes):
+        eng.threshold_combine(bytes(32) + idb[32:], parts, t)                             # id == 0
+
+
+def test_full_size_properties(eng, oracle, M):
+    """BASELINE config 2 size (262144): the oracle cannot sign that many, so tile a small signed set and
+    check size-independent properties: the bitmap equals the closed-form pattern, and flipping one
+    message flips exactly one bit."""
+    dst = M.DEFAULT_DST
+    n = 262144
+    pks, msgs, sigs, exp = synth.make_batch(oracle, n, dst, invalid_every=64, uniq=64)
+    got = eng.verify_batch(pks, msgs, sigs, dst)
+    want = synth.bitmap_of(exp)
+    assert got == want
+    assert sum(exp) == n - n // 64
+    msgs2 = list(msgs); msgs2[123456] = b"flipped"
+    got2 = eng.verify_batch(pks, msgs2, sigs, dst)
+    diff = np.unpackbits(np.frombuffer(got, dtype=np.uint8) ^ np.frombuffer(got2, dtype=np.uint8), bitorder="little")
+    assert diff.sum() == 1 and diff[123456] == 1
+
+
+def test_device_resident_entry_points(eng, oracle, M):
+    torch = pytest.importorskip("torch")
+    dst = M.DEFAULT_DST
+    n = 300
+    pks, msgs, sigs, exp = synth.make_batch(oracle, n, dst, invalid_every=7, uniq=30)
+    data, off = M.engine.pack_messages(msgs)
+    dev = torch.device("cuda:0")
+    t_pk = torch.frombuffer(bytearray(pks), dtype=torch.uint8).to(dev)
+    t_sg = torch.frombuffer(bytearray(sigs), dtype=torch.uint8).to(dev)
+    t_ms = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+    t_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    t_bm = torch.zeros((n + 7) // 8, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    eng.verify_batch_dev(t_pk.data_ptr(), t_ms.data_ptr(), t_off.data_ptr(), t_sg.data_ptr(), n, t_bm.data_ptr(), dst)
+    eng.synchronize()
+    assert bytes(t_bm.cpu().numpy()) == synth.bitmap_of(exp)
