@@ -1,0 +1,109 @@
+"""CPU-only: the DEVICE arithmetic headers compiled for the host with -DBN_CHECK.
+
+Two purposes: (1) the interval discipline of the lazy radix-2^29 limbs (fp29.h) is asserted at every
+multiply on every code path the kernels run -- the tracked bounds are data independent, so one pass
+proves them for all inputs; (2) the exact code the GPU runs is compared with the oracle without a GPU.
+This is a test tool; the product has no CPU path."""
+import ctypes
+import json
+import os
+import random
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SIM = os.path.join(ROOT, "tests", "hostsim")
+
+
+@pytest.fixture(scope="module")
+def hs():
+    so = os.path.join(SIM, "libhostsim.so")
+    src = [os.path.join(SIM, "hostsim.cpp")] + [os.path.join(ROOT, "bls-bn254_amd", "csrc", f)
+                                               for f in os.listdir(os.path.join(ROOT, "bls-bn254_amd", "csrc")) if f.endswith(".h")]
+    if not os.path.exists(so) or any(os.path.getmtime(p) > os.path.getmtime(so) for p in src):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-DBN_CHECK", "-fPIC", "-shared", "-o", so, os.path.join(SIM, "hostsim.cpp")])
+    return ctypes.CDLL(so)
+
+
+def b32(x):
+    return x.to_bytes(32, "big")
+
+
+def test_fp_arithmetic(hs, pyref):
+    P = pyref.P
+    rnd = random.Random(1)
+    out = ctypes.create_string_buffer(32)
+    vals = [0, 1, 2, P - 1, P - 2, 2**253, (1 << 29) - 1, 1 << 232] + [rnd.randrange(P) for _ in range(60)]
+    for x in vals:
+        for y in vals[:12] + [rnd.randrange(P) for _ in range(3)]:
+            hs.hs_fp_mul(b32(x), b32(y), out); assert int.from_bytes(out.raw, "big") == x * y % P
+            hs.hs_fp_mix(b32(x), b32(y), out); assert int.from_bytes(out.raw, "big") == ((x + y) * (x - y) + 9 * x - y) % P
+        hs.hs_fp_sqr(b32(x), out); assert int.from_bytes(out.raw, "big") == x * x % P
+    for x in (0, 1, rnd.randrange(P)):
+        hs.hs_fp_inv(b32(x), out); assert int.from_bytes(out.raw, "big") == pow(x, P - 2, P)      # inv0(0) = 0
+    assert hs.hs_fp_decode_ok(b32(P - 1)) == 1 and hs.hs_fp_decode_ok(b32(P)) == 0 and hs.hs_fp_decode_ok(b"\xff" * 32) == 0
+    for okm in [os.urandom(48) for _ in range(10)] + [b"\xff" * 48, bytes(48)]:
+        hs.hs_fp_from_okm(okm, out); assert int.from_bytes(out.raw, "big") == int.from_bytes(okm, "big") % P
+
+
+def test_pairing_path_bit_exact_and_bounded(hs, oracle, pyref, kats):
+    rnd = random.Random(2)
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    ml = ctypes.create_string_buffer(384); gt = ctypes.create_string_buffer(384); st = ctypes.c_int(0)
+    hs.hs_stats_reset()
+    hs.hs_miller1(G1, G2, ml, ctypes.byref(st))
+    assert st.value == 3 and ml.raw == oracle.miller_loop_batch(G1, G2, 1)
+    assert hs.hs_final_exp(ml.raw, gt) == 0
+    assert gt.raw.hex() == kats["constants"]["gt_generator_bytes_hex"]
+    for _ in range(2):
+        p, q = oracle.g1_mul(G1, rnd.randrange(1, pyref.R)), oracle.g2_mul(G2, rnd.randrange(1, pyref.R))
+        hs.hs_miller1(p, q, ml, ctypes.byref(st)); assert ml.raw == oracle.miller_loop_batch(p, q, 1)
+        hs.hs_pairing(p, q, gt); assert gt.raw == oracle.pairing_batch(p, q, 1)
+    ident = bytes(32) + (1).to_bytes(32, "big")
+    hs.hs_miller1(ident, G2, ml, ctypes.byref(st))
+    assert st.value == 7 and ml.raw == (1).to_bytes(32, "big") + bytes(352)
+    stats = (ctypes.c_double * 8)()
+    hs.hs_stats(stats)
+    assert stats[0] < 2.97 and stats[1] < 2.97 and stats[2] < 167          # proven worst-case budgets (fp29.h)
+
+
+def test_hash_checks_and_verify(hs, oracle, pyref, kats):
+    rnd = random.Random(3)
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    o64 = ctypes.create_string_buffer(64); o128 = ctypes.create_string_buffer(128)
+    g1k = kats["g1"]
+    for v in g1k["hash"]:
+        m = v["msg"].encode(); d = g1k["hash_dst"].encode()
+        hs.hs_hash_to_g1(m, len(m), d, len(d), 1, o64); assert o64.raw.hex() == v["p_x"] + v["p_y"]
+    for v in g1k["encode"][:3]:
+        m = v["msg"].encode(); d = g1k["encode_dst"].encode()
+        hs.hs_hash_to_g1(m, len(m), d, len(d), 0, o64); assert o64.raw.hex() == v["p_x"] + v["p_y"]
+    g2k = kats["g2"]
+    for name, ro in (("hash", 1), ("encode", 0)):
+        for v in g2k[name][:2]:
+            m = v["msg"].encode(); d = g2k[name + "_dst"].encode()
+            hs.hs_hash_to_g2(m, len(m), d, len(d), ro, o128)
+            assert o128.raw.hex() == v["x_c1"] + v["x_c0"] + v["y_c1"] + v["y_c0"]
+    bp = g2k["bad_point"]
+    bad = bytes.fromhex(bp["x_c1"] + bp["x_c0"] + bp["y_c1"] + bp["y_c0"])
+    from tests import synth
+    assert hs.hs_g2_check(G2) == 1 and hs.hs_g2_check(bad) == 0 and hs.hs_g2_check(synth.NON_SUBGROUP_PK) == 0
+    ident = bytes(32) + (1).to_bytes(32, "big")
+    assert hs.hs_g1_check(G1) == 1 and hs.hs_g1_check(ident) == 1 and hs.hs_g1_check(G1[:32] + (3).to_bytes(32, "big")) == 0
+    p = oracle.g1_mul(G1, rnd.randrange(1, pyref.R))
+    hs.hs_g1_add(p, G1, o64); assert o64.raw == oracle.g1_add(p, G1)
+    hs.hs_g1_add(p, p, o64); assert o64.raw == oracle.g1_add(p, p)
+    hs.hs_g1_add(p, ident, o64); assert o64.raw == p
+    k = rnd.randrange(1, pyref.R)
+    hs.hs_g1_mul(p, k.to_bytes(32, "big"), o64); assert o64.raw == oracle.g1_mul(p, k)
+    dst = pyref.DEFAULT_DST
+    sk = rnd.randrange(1, pyref.R)
+    pk = oracle.sk_to_pk(sk); msg = b"hello"; sig = oracle.sign(sk, msg, dst)
+    ml = ctypes.create_string_buffer(384)
+    assert hs.hs_verify(pk, msg, len(msg), sig, dst, len(dst), ml) == 1
+    negG2 = pyref.g2_to_bytes(pyref.g2_neg(pyref.G2_GEN))
+    H = oracle.hash_to_g1_batch([msg], dst)
+    assert ml.raw == oracle.multi_miller_loop(sig + H, negG2 + pk, 2)        # fixed-Q line table == on-the-fly lines
+    assert hs.hs_verify(pk, b"hellp", 5, sig, dst, len(dst), None) == 0
+    assert hs.hs_verify(synth.NON_SUBGROUP_PK, msg, len(msg), sig, dst, len(dst), None) == 0
