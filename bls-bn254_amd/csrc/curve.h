@@ -63,7 +63,7 @@ template <class F> BN_INL Proj<F> proj_from_affine(const Aff<F>& a) {
   return r;
 }
 // complete addition, RCB Alg 7 with a = 0 (g1.rs:744-786, g2.rs:789-831); inputs/outputs normalised
-template <class F> BN_HD inline Proj<F> proj_add(const Proj<F>& a, const Proj<F>& b) {
+template <class F> BN_FUNC Proj<F> proj_add(const Proj<F>& a, const Proj<F>& b) {
   BN_CTX;
   F t0 = f_mul(a.x, b.x), t1 = f_mul(a.y, b.y), t2 = f_mul(a.z, b.z);
   F m3 = f_mul(f_sub(a.x, a.y), f_sub(b.x, b.y));
@@ -83,7 +83,7 @@ template <class F> BN_HD inline Proj<F> proj_add(const Proj<F>& a, const Proj<F>
   return {x3, yy, zz};
 }
 // doubling, RCB Alg 9 (g1.rs:788-818, g2.rs:834-863)
-template <class F> BN_HD inline Proj<F> proj_dbl(const Proj<F>& a) {
+template <class F> BN_FUNC Proj<F> proj_dbl(const Proj<F>& a) {
   BN_CTX;
   F t0 = f_sqr(a.y);
   F z8 = f_lc2<8, 0>(t0, t0);
@@ -103,7 +103,7 @@ template <class F> BN_INL Proj<F> proj_select(bool c, const Proj<F>& a, const Pr
   return {f_select(c, a.x, b.x), f_select(c, a.y, b.y), f_select(c, a.z, b.z)};
 }
 // k * P for a 64-bit public scalar (uniform bits): left-to-right double and add
-template <class F> BN_HD inline Proj<F> proj_mul_u64(const Proj<F>& p, uint64_t k) {
+template <class F> BN_FUNC Proj<F> proj_mul_u64(const Proj<F>& p, uint64_t k) {
   BN_CTX;
   Proj<F> acc = proj_identity<F>();
   for (int i = 63; i >= 0; --i) {
@@ -113,7 +113,7 @@ template <class F> BN_HD inline Proj<F> proj_mul_u64(const Proj<F>& p, uint64_t 
   return acc;
 }
 // k * P for a per-lane 256-bit scalar (4 x u64, little endian): branch-free select per bit
-template <class F> BN_HD inline Proj<F> proj_mul_256(const Proj<F>& p, const uint64_t* k) {
+template <class F> BN_FUNC Proj<F> proj_mul_256(const Proj<F>& p, const uint64_t* k) {
   BN_CTX;
   Proj<F> acc = proj_identity<F>();
   for (int i = 255; i >= 0; --i) {
@@ -148,7 +148,7 @@ BN_INL bool g1_on_curve(const G1A& a) {                          // g1.rs:383-39
   Fp rhs = fp_add(fp_mul(fp_sqr(a.x), a.x), fp_const(bnc::THREE));
   return a.inf | fp_is_zero(fp_sub(fp_sqr(a.y), rhs));
 }
-BN_HD inline G1A g1_to_affine(const G1P& p) {
+BN_FUNC G1A g1_to_affine(const G1P& p) {
   BN_CTX;
   G1A r;
   r.inf = fp_is_zero(p.z);
@@ -175,7 +175,7 @@ BN_INL bool g2_on_curve(const G2A& a) {                          // g2.rs:409-41
   Fp2 rhs = fp2_add(fp2_mul(fp2_sqr(a.x), a.x), fp2_const(bnc::B2));
   return a.inf | fp2_is_zero(fp2_sub(fp2_sqr(a.y), rhs));
 }
-BN_HD inline G2A g2_to_affine(const G2P& p) {
+BN_FUNC G2A g2_to_affine(const G2P& p) {
   BN_CTX;
   G2A r;
   r.inf = fp2_is_zero(p.z);
@@ -192,7 +192,7 @@ BN_INL G2P g2_psi(const G2P& a) {                                // g2.rs:938-95
 // same boolean is obtained from one 63-bit multiplication and the untwist-Frobenius-twist map:
 //   [x+1]P + psi([x]P) + psi^2([x]P) == psi^3([2x]P)
 // (equivalence incl. small-order points is tested against [r]P in tests/test_oracle_golden.py).
-BN_HD inline bool g2_torsion_free(const G2A& a) {
+BN_FUNC bool g2_torsion_free(const G2A& a) {
   BN_CTX;
   G2P p = proj_from_affine(a);
   G2P xp = proj_mul_u64(p, bnc::BN_X);
@@ -201,7 +201,7 @@ BN_HD inline bool g2_torsion_free(const G2A& a) {
   G2P rhs = g2_psi(g2_psi(g2_psi(proj_dbl(xp))));
   return a.inf | proj_eq(lhs, rhs);
 }
-BN_HD inline G2P g2_clear_cofactor(const G2P& p) {               // g2.rs:685-693
+BN_FUNC G2P g2_clear_cofactor(const G2P& p) {               // g2.rs:685-693
   G2P p0 = proj_mul_u64(p, bnc::BN_X);
   G2P p1 = g2_psi(proj_add(proj_dbl(p0), p0));
   G2P p2 = g2_psi(g2_psi(p0));
@@ -213,7 +213,7 @@ BN_HD inline G2P g2_clear_cofactor(const G2P& p) {               // g2.rs:685-69
 // Straight-line Shallue-van de Woestijne (RFC 9380 F.1), Z = 1, following fp.rs:292-370.  The two
 // is_square tests and the final sqrt of the reference (three Euler/sqrt exponentiations) are each
 // done as ONE a^((p+1)/4) exponentiation whose square is compared with a (fp_sqrt_cand).
-BN_HD inline G1A svdw_g1(const Fp& u_in) {
+BN_FUNC G1A svdw_g1(const Fp& u_in) {
   BN_CTX;
   Fp u = fp_norm(u_in);
   Fp c2 = fp_const(bnc::SVDW1_C2), c3 = fp_const(bnc::SVDW1_C3), c4 = fp_const(bnc::SVDW1_C4), one = fp_one(), b = fp_const(bnc::THREE);
@@ -241,14 +241,14 @@ BN_HD inline G1A svdw_g1(const Fp& u_in) {
   return r;
 }
 // hash_to_curve for G1 (g1.rs:910-919): map two field elements, add, no cofactor
-BN_HD inline G1A hash_to_g1_from_fields(const Fp& u0, const Fp& u1) {
+BN_FUNC G1A hash_to_g1_from_fields(const Fp& u0, const Fp& u1) {
   BN_CTX;
   G1A q0 = svdw_g1(u0), q1 = svdw_g1(u1);
   return g1_to_affine(proj_add(proj_from_affine(q0), proj_from_affine(q1)));
 }
 
 // Fp2 helpers for the G2 map
-BN_HD inline Fp2 fp2_pow(const Fp2& a, Exp256 e) {
+BN_FUNC Fp2 fp2_pow(const Fp2& a, Exp256 e) {
   BN_CTX;
   Fp2 base = fp2_norm(a), r = fp2_one();
   for (int i = 255; i >= 0; --i) {
@@ -258,14 +258,14 @@ BN_HD inline Fp2 fp2_pow(const Fp2& a, Exp256 e) {
   }
   return r;
 }
-BN_HD inline bool fp2_is_square(const Fp2& a) {                  // fp2.rs:441-452: norm is a square in Fp
+BN_FUNC bool fp2_is_square(const Fp2& a) {                  // fp2.rs:441-452: norm is a square in Fp
   Fp2 n = fp2_norm(a);
   bool e;
   (void)fp_sqrt_cand(fp_dot2(n.c0, n.c0, n.c1, n.c1), e);
   return e;
 }
 // Algorithm 9 of eprint 2012/685 (fp2.rs:172-218); returns a root when a is a square
-BN_HD inline Fp2 fp2_sqrt(const Fp2& a_in) {
+BN_FUNC Fp2 fp2_sqrt(const Fp2& a_in) {
   BN_CTX;
   Fp2 a = fp2_norm(a_in);
   Fp2 a1 = fp2_pow(a, BN_EXP(EXP_PM3_4));
@@ -277,7 +277,7 @@ BN_HD inline Fp2 fp2_sqrt(const Fp2& a_in) {
   Fp2 r = fp2_mul(b, x0);
   return fp2_select(neg_one, alt, r);
 }
-BN_HD inline G2A svdw_g2(const Fp2& u_in) {                      // fp2.rs:224-286
+BN_FUNC G2A svdw_g2(const Fp2& u_in) {                      // fp2.rs:224-286
   Fp2 u = fp2_norm(u_in);
   Fp2 c1 = fp2_const(bnc::SVDW2_C1), c3 = fp2_const(bnc::SVDW2_C3), c4 = fp2_const(bnc::SVDW2_C4), one = fp2_one(), b = fp2_const(bnc::B2);
   Fp2 c2 = {fp_const(bnc::SVDW1_C2), fp_zero()};

@@ -31,6 +31,13 @@
 #define BN_HD
 #endif
 #define BN_INL BN_HD inline __attribute__((always_inline))
+// BN_FUNC marks the large building blocks (tower multiplications, line steps, exponentiations).  By
+// default the compiler decides whether to outline them; -DBN_FORCE_INLINE inlines them all.
+#ifdef BN_FORCE_INLINE
+#define BN_FUNC BN_INL
+#else
+#define BN_FUNC BN_HD inline
+#endif
 #define BN_UNROLL _Pragma("unroll")
 
 #ifdef BN_CHECK
@@ -405,7 +412,7 @@ BN_INL Fp fp_from_okm(const uint8_t* okm) {
 // 4-bit fixed windows: 252 squarings + 64 multiplies + 14 table products.
 struct Exp256 { uint64_t w[4]; };
 #define BN_EXP(name) (::bn::Exp256{{bnc::name[0], bnc::name[1], bnc::name[2], bnc::name[3]}})
-BN_HD inline Fp fp_pow(const Fp& a, Exp256 e) {
+BN_FUNC Fp fp_pow(const Fp& a, Exp256 e) {
   Fp tab[16];
   tab[0] = fp_one();
   tab[1] = fp_norm(a);
@@ -418,10 +425,10 @@ BN_HD inline Fp fp_pow(const Fp& a, Exp256 e) {
   }
   return r;
 }
-BN_HD inline Fp fp_inv(const Fp& a) { return fp_pow(a, BN_EXP(EXP_PM2)); }                 // inv0(0) = 0 (E15)
+BN_FUNC Fp fp_inv(const Fp& a) { return fp_pow(a, BN_EXP(EXP_PM2)); }                 // inv0(0) = 0 (E15)
 // y = a^((p+1)/4); is_sq = (y^2 == a).  One exponentiation gives Euler's criterion (fp.rs:428-431)
 // and the square root (sqrt_ratio with v = 1, fp.rs:212-243) together.
-BN_HD inline Fp fp_sqrt_cand(const Fp& a, bool& is_sq) {
+BN_FUNC Fp fp_sqrt_cand(const Fp& a, bool& is_sq) {
   Fp y = fp_pow(a, BN_EXP(EXP_PP1_4));
   is_sq = fp_eq(fp_sqr(y), a);
   return y;

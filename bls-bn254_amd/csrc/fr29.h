@@ -71,7 +71,7 @@ BN_INL void fr_to_be(uint8_t* b, const Fr& a) {
   limbs_to_words(w, c.l);
   BN_UNROLL for (int j = 0; j < 8; ++j) store_be32(b + 4 * (7 - j), w[j]);
 }
-BN_HD inline Fr fr_inv(const Fr& a) {                 // a^(r-2)
+BN_FUNC Fr fr_inv(const Fr& a) {                 // a^(r-2)
   Fr r = fr_const(bnc::FR_ONE);
   for (int i = 255; i >= 0; --i) {
     r = fr_mul(r, r);
@@ -83,7 +83,7 @@ BN_HD inline Fr fr_inv(const Fr& a) {                 // a^(r-2)
 }
 // lambda_i for lane i over the t ids (32 B big-endian each).  ok = all ids decode, are non-zero and
 // id_i differs from every other id.
-BN_HD inline Fr lagrange_at_zero(const uint8_t* ids, size_t t, size_t i, bool& ok) {
+BN_FUNC Fr lagrange_at_zero(const uint8_t* ids, size_t t, size_t i, bool& ok) {
   bool oki;
   Fr xi = fr_from_be(ids + 32 * i, oki);
   ok = oki & !fr_is_zero(xi);

@@ -1,17 +1,4 @@
-// kernels.hip -- HIP kernels (gfx950) and the C-ABI host side of the BLS-BN254 verification engine.
-//
-// One lane = one tuple.  The hot path is split into phase kernels whose per-tuple state lives in HBM
-// in limb-major layout (ws[k * n + i]: coalesced 256-B wave accesses), because the live state of a
-// phase (f in Fp12 = 108 dwords, T = 54, line = 54, ...) exceeds what can stay in registers across
-// phases at two waves per SIMD; the HBM traffic this costs is ~1 KB per tuple per phase against
-// millions of VALU operations (DESIGN.md "Roofline").
-//
-//   k_hash_to_g1      msgs -> H(msg) (XMD-SHA-256 + 2x SVDW + add)          g1.rs:910-919
-//   k_g2_check        pk   -> decodes && on curve && in the r-torsion        g2.rs:350-414,:733-736
-//   k_miller_verify   (sig, H, pk) -> f = ML(sig,-G2gen) * ML(H,pk)          pairings.rs:808-857
-//   k_final_exp       f -> f^((p^12-1)/r * 2x(6x^2+3x+1)); == 1 -> bitmap   pairings.rs:50-178
-//   k_miller_1, k_fp12_* , k_g1_* ...  the primitive / aggregate / threshold entry points
-//
+// host.hip -- C-ABI host side (include/blsbn254.h): contexts, workspace, staging, kernel launches.
 // There is no CPU fallback in this file: every entry point launches kernels or fails.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -20,205 +7,12 @@
 #include <string>
 #include <vector>
 
-#define BN_WANT_LINE_TABLE
-#define BN_LINE_TABLE_QUAL __device__ const
-#include "lane_ops.h"
-#include "fr29.h"
+#include "sha256.h"      // host-side use: pre-hashing an oversize DST only (RFC 9380 5.3.3)
+#include "lane_ops.h"    // flag constants
+#include "kernels.h"
 #include "../../include/blsbn254.h"
 
 using namespace bn;
-
-#ifndef BN_WAVES_PER_SIMD
-#define BN_WAVES_PER_SIMD 1
-#endif
-#define BN_KERNEL __global__ void __launch_bounds__(256, BN_WAVES_PER_SIMD)
-
-__device__ const int8_t d_ate_naf[bnc::ATE_NAF_LEN] = BN_ATE_NAF_INIT;
-
-// ------------------------------------------------------------------ kernels
-// ok bit per tuple -> LSB-first bitmap, one 64-bit ballot per wave
-__device__ inline void write_ballot(uint8_t* bitmap, size_t n, size_t i, bool bit) {
-  unsigned long long m = __ballot(bit);
-  unsigned lane = threadIdx.x & 63;
-  size_t base = (i - lane) >> 3;                       // first byte of this wave's 64 tuples
-  size_t nbytes = (n + 7) >> 3;
-  if (lane < 8 && base + lane < nbytes) bitmap[base + lane] = (uint8_t)(m >> (8 * lane));
-}
-
-// mode: 0 = hash (RO) -> 18 limbs into h_ws ; 1 = hash -> 64 bytes ; 2 = encode (NU) -> 64 bytes
-BN_KERNEL k_hash_to_g1(const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
-                       int32_t* h_ws, uint8_t* out_bytes, int mode) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint8_t* m = msgs + off[i];
-  size_t len = (size_t)(off[i + 1] - off[i]);
-  G1A h = mode == 2 ? lane_encode_to_g1(m, len, dst, dst_len) : lane_hash_to_g1(m, len, dst, dst_len);
-  if (mode == 0) { store_fp(h_ws + i, n, h.x); store_fp(h_ws + 9 * n + i, n, h.y); }
-  else g1_encode(out_bytes + 64 * i, h);
-}
-BN_KERNEL k_hash_to_g2(const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
-                       uint8_t* out_bytes, int ro) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  g2_encode(out_bytes + 128 * i, lane_hash_to_g2(msgs + off[i], (size_t)(off[i + 1] - off[i]), dst, dst_len, ro != 0));
-}
-BN_KERNEL k_g1_check(const uint8_t* g1, size_t n, uint8_t* bitmap) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool ok = i < n ? lane_g1_check(g1 + 64 * i) : false;
-  write_ballot(bitmap, n, i, ok);
-}
-// out: byte per tuple (ok_bytes) and/or bitmap
-BN_KERNEL k_g2_check(const uint8_t* g2, size_t n, uint8_t* ok_bytes, uint8_t* bitmap) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool ok = i < n ? lane_g2_check(g2 + 128 * i) : false;
-  if (ok_bytes && i < n) ok_bytes[i] = ok;
-  if (bitmap) write_ballot(bitmap, n, i, ok);
-}
-// per-pair Miller loop; P either 64 bytes (g1) or 18 limbs in p_ws (then p_ok taken from p_flags)
-BN_KERNEL k_miller_1(const uint8_t* g1, const uint8_t* g2, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint8_t st;
-  Fp12 f = lane_miller_1(g1 + 64 * i, g2 + 128 * i, d_ate_naf, bnc::ATE_NAF_LEN, st);
-  fp12_store_limbs(f_ws + i, f_stride, f);
-  status[i] = st;
-}
-// aggregate verify: P = H(msg_i) from h_ws, Q = pk_i; flags: bit0 pk decodes/on curve/non-identity
-BN_KERNEL k_miller_hpk(const int32_t* h_ws, const uint8_t* pks, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* flags) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  bool okp;
-  G2A pk = g2_decode(pks + 128 * i, okp);
-  bool pk_ok = okp & !pk.inf & g2_on_curve(pk);
-  pk.x = fp2_select(pk_ok, pk.x, fp2_const(bnc::G2_GEN_X)); pk.y = fp2_select(pk_ok, pk.y, fp2_const(bnc::G2_GEN_Y));
-  pk.inf = false;
-  G1A h; h.x = load_fp(h_ws + i, n); h.y = load_fp(h_ws + 9 * n + i, n); h.inf = false;
-  fp12_store_limbs(f_ws + i, f_stride, miller_loop_1(h, pk, d_ate_naf, bnc::ATE_NAF_LEN));
-  flags[i] = pk_ok ? 1 : 0;
-}
-BN_KERNEL k_miller_verify(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n, int32_t* f_ws, uint8_t* flags) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  G1A h; h.x = load_fp(h_ws + i, n); h.y = load_fp(h_ws + 9 * n + i, n); h.inf = false;
-  uint8_t fl;
-  Fp12 f = lane_miller_verify(pks + 128 * i, sigs + 64 * i, h, d_ate_naf, bnc::ATE_NAF_LEN, BN_NEG_G2_LINE_TABLE, fl);
-  fp12_store_limbs(f_ws + i, n, f);
-  flags[i] = fl;
-}
-// mode 0: verify -> bitmap bit = flags ok && subgroup ok && FE(f) == 1
-// mode 1: pairing -> gt bytes (identity status -> one); mode 2: plain final exponentiation -> bytes
-BN_KERNEL k_final_exp(const int32_t* f_ws, size_t n, size_t f_stride, const uint8_t* flags, const uint8_t* sub_ok,
-                      uint8_t* bitmap, uint8_t* gt_bytes, int mode) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool bit = false;
-  if (i < n) {
-    Fp12 f = final_exponentiation(fp12_load_limbs(f_ws + i, f_stride));
-    if (mode == 0) bit = fp12_is_one(f) & (flags[i] == (FLAG_SIG_OK | FLAG_PK_OK)) & (sub_ok[i] != 0);
-    else fp12_to_be(gt_bytes + 384 * i, f);
-  }
-  if (mode == 0) write_ballot(bitmap, n, i, bit);
-}
-BN_KERNEL k_fp12_from_bytes(const uint8_t* in, size_t n, int32_t* f_ws, uint8_t* status) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  bool ok;
-  Fp12 f = fp12_from_be(in + 384 * i, ok);
-  fp12_store_limbs(f_ws + i, n, f);
-  status[i] = ok ? 1 : 0;
-}
-BN_KERNEL k_fp12_to_bytes(const int32_t* f_ws, size_t n, size_t stride, uint8_t* out) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  fp12_to_be(out + 384 * i, fp12_load_limbs(f_ws + i, stride));
-}
-// product tree level: out[i] = in[2i] * in[2i+1] (or in[2i] when 2i+1 == n_in)
-BN_KERNEL k_fp12_mul_pairs(const int32_t* in, size_t n_in, size_t in_stride, int32_t* out, size_t out_stride) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t n_out = (n_in + 1) >> 1;
-  if (i >= n_out) return;
-  Fp12 a = fp12_load_limbs(in + 2 * i, in_stride);
-  if (2 * i + 1 < n_in) a = fp12_mul(a, fp12_load_limbs(in + 2 * i + 1, in_stride));
-  fp12_store_limbs(out + i, out_stride, a);
-}
-// G1 sums (aggregate_sigs, threshold_combine): projective points as 27 limbs, limb-major
-__device__ inline void store_g1p(int32_t* ws, size_t stride, const G1P& p) {
-  store_fp(ws, stride, p.x); store_fp(ws + 9 * stride, stride, p.y); store_fp(ws + 18 * stride, stride, p.z);
-}
-__device__ inline G1P load_g1p(const int32_t* ws, size_t stride) {
-  return {load_fp(ws, stride), load_fp(ws + 9 * stride, stride), load_fp(ws + 18 * stride, stride)};
-}
-// scalars: NULL (plain load) or n x 32 B big-endian (threshold: lambda_i * sig_i)
-BN_KERNEL k_g1_load(const uint8_t* g1, const uint8_t* scalars, size_t n, int32_t* ws, uint8_t* status) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  bool ok;
-  G1A a = g1_decode(g1 + 64 * i, ok);
-  G1P p = proj_from_affine(a);
-  if (scalars) {
-    uint64_t k[4];
-    for (int w = 0; w < 4; ++w) {
-      uint64_t v = 0;
-      for (int j = 0; j < 8; ++j) v = (v << 8) | scalars[32 * i + 8 * (3 - w) + j];
-      k[w] = v;
-    }
-    p = proj_mul_256(p, k);
-  }
-  store_g1p(ws + i, n, p);
-  status[i] = ok ? 1 : 0;
-}
-BN_KERNEL k_g1_add_pairs(const int32_t* in, size_t n_in, size_t in_stride, int32_t* out, size_t out_stride) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t n_out = (n_in + 1) >> 1;
-  if (i >= n_out) return;
-  G1P a = load_g1p(in + 2 * i, in_stride);
-  if (2 * i + 1 < n_in) a = proj_add(a, load_g1p(in + 2 * i + 1, in_stride));
-  store_g1p(out + i, out_stride, a);
-}
-BN_KERNEL k_g1_to_bytes(const int32_t* ws, size_t stride, uint8_t* out) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  g1_encode(out, g1_to_affine(load_g1p(ws, stride)));
-}
-// threshold: lane i -> lambda_i as 32 big-endian bytes (scalars for k_g1_load); status 1 = ok
-BN_KERNEL k_lagrange(const uint8_t* ids, size_t t, uint8_t* scalars, uint8_t* status) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= t) return;
-  bool ok;
-  Fr lam = lagrange_at_zero(ids, t, i, ok);
-  fr_to_be(scalars + 32 * i, lam);
-  status[i] = ok ? 1 : 0;
-}
-// VALU roofline probe: independent v_mad_u64_u32 chains, every CU busy (the denominator of
-// bench.py's roofline.frac is measured in the same run, BASELINE.md section 3 "same-run rule")
-__global__ void __launch_bounds__(256) k_valu_peak(uint32_t* out, uint32_t seed, int iters) {
-  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t a = seed * 2654435761u + tid, b = (seed ^ 0x9e3779b9u) + tid * 7u;
-  uint64_t acc[8];
-  for (int c = 0; c < 8; ++c) acc[c] = tid + c;
-  for (int i = 0; i < iters; ++i) {
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      uint64_t r;
-      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc[c]) : "vcc");
-      acc[c] = r;
-    }
-  }
-  uint64_t s = 0;
-  for (int c = 0; c < 8; ++c) s ^= acc[c];
-  out[tid] = (uint32_t)s ^ (uint32_t)(s >> 32);
-}
-// status reductions
-__global__ void k_status_reduce(const uint8_t* status, size_t n, uint8_t want_mask, uint8_t want_val, int* first_bad) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && (status[i] & want_mask) != want_val) atomicMin(first_bad, (int)(i > 0x7ffffffe ? 0x7ffffffe : i));
-}
-__global__ void k_and_reduce(const uint8_t* flags, const uint8_t* sub_ok, size_t n, int* all_ok) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n && (flags[i] != 1 || sub_ok[i] == 0)) atomicAnd(all_ok, 0);
-}
-BN_KERNEL k_final_exp_is_one(const int32_t* f_ws, size_t stride, int* out) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  *out = fp12_is_one(final_exponentiation(fp12_load_limbs(f_ws, stride))) ? 1 : 0;
-}
 
 // ------------------------------------------------------------------ host side
 struct DevBuf {

@@ -1,0 +1,132 @@
+// k_misc.hip -- hash-to-curve, point checks, product / sum trees, Lagrange coefficients, reductions,
+// and the VALU roofline probe.
+#include "lane_ops.h"
+#include "fr29.h"
+#include "kernels.h"
+using namespace bn;
+
+__device__ inline void write_ballot(uint8_t* bitmap, size_t n, size_t i, bool bit) {
+  unsigned long long m = __ballot(bit);
+  unsigned lane = threadIdx.x & 63;
+  size_t base = (i - lane) >> 3;                       // first byte of this wave's 64 tuples
+  size_t nbytes = (n + 7) >> 3;
+  if (lane < 8 && base + lane < nbytes) bitmap[base + lane] = (uint8_t)(m >> (8 * lane));
+}
+
+__device__ inline void store_g1p(int32_t* ws, size_t stride, const G1P& p) {
+  store_fp(ws, stride, p.x); store_fp(ws + 9 * stride, stride, p.y); store_fp(ws + 18 * stride, stride, p.z);
+}
+__device__ inline G1P load_g1p(const int32_t* ws, size_t stride) {
+  return {load_fp(ws, stride), load_fp(ws + 9 * stride, stride), load_fp(ws + 18 * stride, stride)};
+}
+BN_KERNEL k_hash_to_g1(const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
+                       int32_t* h_ws, uint8_t* out_bytes, int mode) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* m = msgs + off[i];
+  size_t len = (size_t)(off[i + 1] - off[i]);
+  G1A h = mode == 2 ? lane_encode_to_g1(m, len, dst, dst_len) : lane_hash_to_g1(m, len, dst, dst_len);
+  if (mode == 0) { store_fp(h_ws + i, n, h.x); store_fp(h_ws + 9 * n + i, n, h.y); }
+  else g1_encode(out_bytes + 64 * i, h);
+}
+BN_KERNEL k_hash_to_g2(const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
+                       uint8_t* out_bytes, int ro) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g2_encode(out_bytes + 128 * i, lane_hash_to_g2(msgs + off[i], (size_t)(off[i + 1] - off[i]), dst, dst_len, ro != 0));
+}
+BN_KERNEL k_g1_check(const uint8_t* g1, size_t n, uint8_t* bitmap) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = i < n ? lane_g1_check(g1 + 64 * i) : false;
+  write_ballot(bitmap, n, i, ok);
+}
+BN_KERNEL k_g2_check(const uint8_t* g2, size_t n, uint8_t* ok_bytes, uint8_t* bitmap) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = i < n ? lane_g2_check(g2 + 128 * i) : false;
+  if (ok_bytes && i < n) ok_bytes[i] = ok;
+  if (bitmap) write_ballot(bitmap, n, i, ok);
+}
+BN_KERNEL k_fp12_from_bytes(const uint8_t* in, size_t n, int32_t* f_ws, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool ok;
+  Fp12 f = fp12_from_be(in + 384 * i, ok);
+  fp12_store_limbs(f_ws + i, n, f);
+  status[i] = ok ? 1 : 0;
+}
+BN_KERNEL k_fp12_to_bytes(const int32_t* f_ws, size_t n, size_t stride, uint8_t* out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fp12_to_be(out + 384 * i, fp12_load_limbs(f_ws + i, stride));
+}
+BN_KERNEL k_fp12_mul_pairs(const int32_t* in, size_t n_in, size_t in_stride, int32_t* out, size_t out_stride) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t n_out = (n_in + 1) >> 1;
+  if (i >= n_out) return;
+  Fp12 a = fp12_load_limbs(in + 2 * i, in_stride);
+  if (2 * i + 1 < n_in) a = fp12_mul(a, fp12_load_limbs(in + 2 * i + 1, in_stride));
+  fp12_store_limbs(out + i, out_stride, a);
+}
+BN_KERNEL k_g1_load(const uint8_t* g1, const uint8_t* scalars, size_t n, int32_t* ws, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool ok;
+  G1A a = g1_decode(g1 + 64 * i, ok);
+  G1P p = proj_from_affine(a);
+  if (scalars) {
+    uint64_t k[4];
+    for (int w = 0; w < 4; ++w) {
+      uint64_t v = 0;
+      for (int j = 0; j < 8; ++j) v = (v << 8) | scalars[32 * i + 8 * (3 - w) + j];
+      k[w] = v;
+    }
+    p = proj_mul_256(p, k);
+  }
+  store_g1p(ws + i, n, p);
+  status[i] = ok ? 1 : 0;
+}
+BN_KERNEL k_g1_add_pairs(const int32_t* in, size_t n_in, size_t in_stride, int32_t* out, size_t out_stride) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t n_out = (n_in + 1) >> 1;
+  if (i >= n_out) return;
+  G1P a = load_g1p(in + 2 * i, in_stride);
+  if (2 * i + 1 < n_in) a = proj_add(a, load_g1p(in + 2 * i + 1, in_stride));
+  store_g1p(out + i, out_stride, a);
+}
+BN_KERNEL k_g1_to_bytes(const int32_t* ws, size_t stride, uint8_t* out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  g1_encode(out, g1_to_affine(load_g1p(ws, stride)));
+}
+BN_KERNEL k_lagrange(const uint8_t* ids, size_t t, uint8_t* scalars, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= t) return;
+  bool ok;
+  Fr lam = lagrange_at_zero(ids, t, i, ok);
+  fr_to_be(scalars + 32 * i, lam);
+  status[i] = ok ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_valu_peak(uint32_t* out, uint32_t seed, int iters) {
+  uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t a = seed * 2654435761u + tid, b = (seed ^ 0x9e3779b9u) + tid * 7u;
+  uint64_t acc[8];
+  for (int c = 0; c < 8; ++c) acc[c] = tid + c;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      uint64_t r;
+      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc[c]) : "vcc");
+      acc[c] = r;
+    }
+  }
+  uint64_t s = 0;
+  for (int c = 0; c < 8; ++c) s ^= acc[c];
+  out[tid] = (uint32_t)s ^ (uint32_t)(s >> 32);
+}
+__global__ void k_status_reduce(const uint8_t* status, size_t n, uint8_t want_mask, uint8_t want_val, int* first_bad) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && (status[i] & want_mask) != want_val) atomicMin(first_bad, (int)(i > 0x7ffffffe ? 0x7ffffffe : i));
+}
+__global__ void k_and_reduce(const uint8_t* flags, const uint8_t* sub_ok, size_t n, int* all_ok) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && (flags[i] != 1 || sub_ok[i] == 0)) atomicAnd(all_ok, 0);
+}

@@ -1,0 +1,33 @@
+// kernels.h -- declarations of the phase kernels (defined in k_miller.hip, k_finalexp.hip, k_misc.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifndef BN_WAVES_PER_SIMD
+#define BN_WAVES_PER_SIMD 1
+#endif
+#define BN_KERNEL __global__ void __launch_bounds__(256, BN_WAVES_PER_SIMD)
+
+BN_KERNEL k_hash_to_g1(const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
+                       int32_t* h_ws, uint8_t* out_bytes, int mode);
+BN_KERNEL k_hash_to_g2(const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
+                       uint8_t* out_bytes, int ro);
+BN_KERNEL k_g1_check(const uint8_t* g1, size_t n, uint8_t* bitmap);
+BN_KERNEL k_g2_check(const uint8_t* g2, size_t n, uint8_t* ok_bytes, uint8_t* bitmap);
+BN_KERNEL k_miller_1(const uint8_t* g1, const uint8_t* g2, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status);
+BN_KERNEL k_miller_hpk(const int32_t* h_ws, const uint8_t* pks, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* flags);
+BN_KERNEL k_miller_verify(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n, int32_t* f_ws, uint8_t* flags);
+BN_KERNEL k_final_exp(const int32_t* f_ws, size_t n, size_t f_stride, const uint8_t* flags, const uint8_t* sub_ok,
+                      uint8_t* bitmap, uint8_t* gt_bytes, int mode);
+BN_KERNEL k_fp12_from_bytes(const uint8_t* in, size_t n, int32_t* f_ws, uint8_t* status);
+BN_KERNEL k_fp12_to_bytes(const int32_t* f_ws, size_t n, size_t stride, uint8_t* out);
+BN_KERNEL k_fp12_mul_pairs(const int32_t* in, size_t n_in, size_t in_stride, int32_t* out, size_t out_stride);
+BN_KERNEL k_g1_load(const uint8_t* g1, const uint8_t* scalars, size_t n, int32_t* ws, uint8_t* status);
+BN_KERNEL k_g1_add_pairs(const int32_t* in, size_t n_in, size_t in_stride, int32_t* out, size_t out_stride);
+BN_KERNEL k_g1_to_bytes(const int32_t* ws, size_t stride, uint8_t* out);
+BN_KERNEL k_lagrange(const uint8_t* ids, size_t t, uint8_t* scalars, uint8_t* status);
+__global__ void __launch_bounds__(256) k_valu_peak(uint32_t* out, uint32_t seed, int iters);
+__global__ void k_status_reduce(const uint8_t* status, size_t n, uint8_t want_mask, uint8_t want_val, int* first_bad);
+__global__ void k_and_reduce(const uint8_t* flags, const uint8_t* sub_ok, size_t n, int* all_ok);
+BN_KERNEL k_final_exp_is_one(const int32_t* f_ws, size_t stride, int* out);

@@ -14,11 +14,11 @@ namespace bn {
 
 enum : uint8_t { FLAG_SIG_OK = 1, FLAG_PK_OK = 2, FLAG_PK_SUBGROUP = 4, FLAG_IDENTITY = 8 };
 
-BN_HD inline void store_fp(int32_t* ws, size_t stride, const Fp& a) {
+BN_FUNC void store_fp(int32_t* ws, size_t stride, const Fp& a) {
   Fp c = fp_canon(a);
   for (int k = 0; k < NL; ++k) ws[(size_t)k * stride] = c.l[k];
 }
-BN_HD inline Fp load_fp(const int32_t* ws, size_t stride) {
+BN_FUNC Fp load_fp(const int32_t* ws, size_t stride) {
   Fp r;
   for (int k = 0; k < NL; ++k) r.l[k] = ws[(size_t)k * stride];
   BN_TRK(set_trk(r, 0, 1, 0, 0.006, 1);)
@@ -26,17 +26,17 @@ BN_HD inline Fp load_fp(const int32_t* ws, size_t stride) {
 }
 
 // ---- hash_to_g1: msg -> H(msg) in G1 (g1.rs:910-919).  out: 18 limbs (x, y), Montgomery canonical.
-BN_HD inline G1A lane_hash_to_g1(const uint8_t* msg, size_t msg_len, const uint8_t* dst, uint32_t dst_len) {
+BN_FUNC G1A lane_hash_to_g1(const uint8_t* msg, size_t msg_len, const uint8_t* dst, uint32_t dst_len) {
   uint8_t okm[96];
   expand_message_xmd(okm, 96, msg, msg_len, dst, dst_len);
   return hash_to_g1_from_fields(fp_from_okm(okm), fp_from_okm(okm + 48));
 }
-BN_HD inline G1A lane_encode_to_g1(const uint8_t* msg, size_t msg_len, const uint8_t* dst, uint32_t dst_len) {   // g1.rs:922-928
+BN_FUNC G1A lane_encode_to_g1(const uint8_t* msg, size_t msg_len, const uint8_t* dst, uint32_t dst_len) {   // g1.rs:922-928
   uint8_t okm[48];
   expand_message_xmd(okm, 48, msg, msg_len, dst, dst_len);
   return svdw_g1(fp_from_okm(okm));
 }
-BN_HD inline G2A lane_hash_to_g2(const uint8_t* msg, size_t msg_len, const uint8_t* dst, uint32_t dst_len, bool ro) {  // g2.rs:919-936
+BN_FUNC G2A lane_hash_to_g2(const uint8_t* msg, size_t msg_len, const uint8_t* dst, uint32_t dst_len, bool ro) {  // g2.rs:919-936
   uint8_t okm[192];
   expand_message_xmd(okm, ro ? 192 : 96, msg, msg_len, dst, dst_len);
   Fp2 u0 = {fp_from_okm(okm), fp_from_okm(okm + 48)};
@@ -49,14 +49,14 @@ BN_HD inline G2A lane_hash_to_g2(const uint8_t* msg, size_t msg_len, const uint8
 }
 
 // ---- point checks
-BN_HD inline bool lane_g1_check(const uint8_t* g1) { bool ok; G1A p = g1_decode(g1, ok); return ok & g1_on_curve(p); }
-BN_HD inline bool lane_g2_check(const uint8_t* g2) {
+BN_FUNC bool lane_g1_check(const uint8_t* g1) { bool ok; G1A p = g1_decode(g1, ok); return ok & g1_on_curve(p); }
+BN_FUNC bool lane_g2_check(const uint8_t* g2) {
   bool ok; G2A q = g2_decode(g2, ok);
   return ok & g2_on_curve(q) & g2_torsion_free(q);
 }
 
 // ---- Miller loops.  status bit0: g1 decoded, bit1: g2 decoded, bit2: either point is the identity.
-BN_HD inline Fp12 lane_miller_1(const uint8_t* g1, const uint8_t* g2, const int8_t* naf, int naf_len, uint8_t& status) {
+BN_FUNC Fp12 lane_miller_1(const uint8_t* g1, const uint8_t* g2, const int8_t* naf, int naf_len, uint8_t& status) {
   bool ok1, ok2;
   G1A p = g1_decode(g1, ok1);
   G2A q = g2_decode(g2, ok2);
@@ -78,7 +78,7 @@ BN_HD inline Fp12 lane_miller_1(const uint8_t* g1, const uint8_t* g2, const int8
   return f;
 }
 // verify: f = ML(sig, -G2gen) * ML(H, pk); flags = FLAG_SIG_OK | FLAG_PK_OK when decodable, on curve, non-identity
-BN_HD inline Fp12 lane_miller_verify(const uint8_t* pk_b, const uint8_t* sig_b, const G1A& h, const int8_t* naf, int naf_len,
+BN_FUNC Fp12 lane_miller_verify(const uint8_t* pk_b, const uint8_t* sig_b, const G1A& h, const int8_t* naf, int naf_len,
                                      const int32_t (*table)[54], uint8_t& flags) {
   bool oks, okp;
   G1A sig = g1_decode(sig_b, oks);

@@ -19,7 +19,7 @@ struct G2J { Fp2 x, y, z; };     // Jacobian running point T of the Miller loop
 struct Line { Fp2 c0, c1, c2; };  // l = c0*yP + c1*xP*w + c2*w^3
 
 // T <- 2T, returns the tangent line coefficients (pairings.rs:901-930).  T normalised in and out.
-BN_HD inline Line doubling_step(G2J& r) {
+BN_FUNC Line doubling_step(G2J& r) {
   BN_CTX;
   Fp2 tmp0 = fp2_sqr(r.x);
   Fp2 tmp1 = fp2_sqr(r.y);
@@ -42,7 +42,7 @@ BN_HD inline Line doubling_step(G2J& r) {
   return l;
 }
 // T <- T + Q (Q affine), returns the chord line coefficients (pairings.rs:932-962)
-BN_HD inline Line addition_step(G2J& r, const Fp2& qx, const Fp2& qy) {
+BN_FUNC Line addition_step(G2J& r, const Fp2& qx, const Fp2& qy) {
   BN_CTX;
   Fp2 zsq = fp2_sqr(r.z);
   Fp2 ysq = fp2_sqr(qy);
@@ -70,7 +70,7 @@ BN_HD inline Line addition_step(G2J& r, const Fp2& qx, const Fp2& qy) {
   return l;
 }
 // f * l(P): scale the line by the G1 point and multiply sparsely (pairings.rs:888-899, slots 0/3/4)
-BN_HD inline Fp12 ell(const Fp12& f, const Line& l, const Fp& px, const Fp& py) {
+BN_FUNC Fp12 ell(const Fp12& f, const Line& l, const Fp& px, const Fp& py) {
   BN_CTX;
   return fp12_mul_by_034(f, fp2_mul_fp(l.c0, py), fp2_mul_fp(l.c1, px), l.c2);
 }
@@ -79,7 +79,7 @@ BN_INL Line line_from_table(const int32_t* t) {                  // 54 strict li
 }
 
 // One-pair Miller loop f_{6x+2,Q}(P) * l_{T,pi(Q)}(P) * l_{T+pi(Q),-pi^2(Q)}(P)
-BN_HD inline Fp12 miller_loop_1(const G1A& p, const G2A& q, const int8_t* naf, int naf_len) {
+BN_FUNC Fp12 miller_loop_1(const G1A& p, const G2A& q, const int8_t* naf, int naf_len) {
   BN_CTX;
   Fp12 f = fp12_one();
   G2J T = {q.x, q.y, fp2_one()};
@@ -101,7 +101,7 @@ BN_HD inline Fp12 miller_loop_1(const G1A& p, const G2A& q, const int8_t* naf, i
 
 // Two-pair loop of the verify equation: e(sig, -G2gen) * e(H, pk), the first pair's lines read from
 // the precomputed table (uniform address: every lane of the wave reads the same entry).
-BN_HD inline Fp12 miller_loop_verify(const G1A& sig, const G1A& h, const G2A& pk, const int8_t* naf, int naf_len,
+BN_FUNC Fp12 miller_loop_verify(const G1A& sig, const G1A& h, const G2A& pk, const int8_t* naf, int naf_len,
                                      const int32_t (*table)[54]) {
   BN_CTX;
   Fp12 f = fp12_one();
@@ -130,7 +130,7 @@ BN_HD inline Fp12 miller_loop_verify(const G1A& sig, const G1A& h, const G2A& pk
 }
 
 // f^x for the BN parameter x (63 bits, x > 0), f in the cyclotomic subgroup
-BN_HD inline Fp12 cyclotomic_exp_x(const Fp12& f) {
+BN_FUNC Fp12 cyclotomic_exp_x(const Fp12& f) {
   BN_CTX;
   Fp12 r = f;
   for (int i = 61; i >= 0; --i) {
@@ -139,7 +139,7 @@ BN_HD inline Fp12 cyclotomic_exp_x(const Fp12& f) {
   }
   return r;
 }
-BN_HD inline Fp12 final_exponentiation(const Fp12& f) {
+BN_FUNC Fp12 final_exponentiation(const Fp12& f) {
   BN_CTX;
   // easy part: f^((p^6-1)(p^2+1))
   Fp12 t = fp12_mul(fp12_conj(f), fp12_inv(f));
@@ -166,12 +166,12 @@ BN_HD inline Fp12 final_exponentiation(const Fp12& f) {
 }
 
 // Gt byte layout (Gt::to_repr / from_repr, pairings.rs:499-579): c0.c0.c0, c0.c0.c1, c0.c1.c0, ...
-BN_HD inline void fp12_to_be(uint8_t* out, const Fp12& a) {
+BN_FUNC void fp12_to_be(uint8_t* out, const Fp12& a) {
   BN_CTX;
   const Fp2* s[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
   for (int i = 0; i < 6; ++i) { fp_to_be(out + 64 * i, s[i]->c0); fp_to_be(out + 64 * i + 32, s[i]->c1); }
 }
-BN_HD inline Fp12 fp12_from_be(const uint8_t* in, bool& ok) {
+BN_FUNC Fp12 fp12_from_be(const uint8_t* in, bool& ok) {
   BN_CTX;
   Fp12 a;
   Fp2* s[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
@@ -184,7 +184,7 @@ BN_HD inline Fp12 fp12_from_be(const uint8_t* in, bool& ok) {
   return a;
 }
 // Device-side workspace form of an Fp12: 108 strict limbs (canonical Montgomery), c0.c0.c0 first.
-BN_HD inline void fp12_store_limbs(int32_t* out, size_t stride, const Fp12& a) {
+BN_FUNC void fp12_store_limbs(int32_t* out, size_t stride, const Fp12& a) {
   BN_CTX;
   const Fp2* s[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
   for (int i = 0; i < 6; ++i) {
@@ -192,7 +192,7 @@ BN_HD inline void fp12_store_limbs(int32_t* out, size_t stride, const Fp12& a) {
     for (int k = 0; k < NL; ++k) { out[(size_t)(18 * i + k) * stride] = c0.l[k]; out[(size_t)(18 * i + 9 + k) * stride] = c1.l[k]; }
   }
 }
-BN_HD inline Fp12 fp12_load_limbs(const int32_t* in, size_t stride) {
+BN_FUNC Fp12 fp12_load_limbs(const int32_t* in, size_t stride) {
   BN_CTX;
   Fp12 a;
   Fp2* s[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};

@@ -17,7 +17,7 @@ struct Sha256 {
 
 BN_INL uint32_t ror32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
 
-BN_HD inline void sha256_compress(uint32_t* h, const uint32_t* blk) {
+BN_FUNC void sha256_compress(uint32_t* h, const uint32_t* blk) {
   const uint32_t K[64] = {
       0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
       0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
@@ -44,13 +44,13 @@ BN_HD inline void sha256_compress(uint32_t* h, const uint32_t* blk) {
   }
   h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
 }
-BN_HD inline void sha256_init(Sha256& s) {
+BN_FUNC void sha256_init(Sha256& s) {
   s.h[0] = 0x6a09e667; s.h[1] = 0xbb67ae85; s.h[2] = 0x3c6ef372; s.h[3] = 0xa54ff53a;
   s.h[4] = 0x510e527f; s.h[5] = 0x9b05688c; s.h[6] = 0x1f83d9ab; s.h[7] = 0x5be0cd19;
   for (int i = 0; i < 16; ++i) s.w[i] = 0;
   s.fill = 0; s.total = 0;
 }
-BN_HD inline void sha256_byte(Sha256& s, uint8_t b) {
+BN_FUNC void sha256_byte(Sha256& s, uint8_t b) {
   uint32_t k = s.fill >> 2, sh = 24 - 8 * (s.fill & 3);
   s.w[k] |= (uint32_t)b << sh;
   ++s.fill; ++s.total;
@@ -60,8 +60,8 @@ BN_HD inline void sha256_byte(Sha256& s, uint8_t b) {
     s.fill = 0;
   }
 }
-BN_HD inline void sha256_update(Sha256& s, const uint8_t* p, size_t n) { for (size_t i = 0; i < n; ++i) sha256_byte(s, p[i]); }
-BN_HD inline void sha256_final(Sha256& s, uint8_t* out) {
+BN_FUNC void sha256_update(Sha256& s, const uint8_t* p, size_t n) { for (size_t i = 0; i < n; ++i) sha256_byte(s, p[i]); }
+BN_FUNC void sha256_final(Sha256& s, uint8_t* out) {
   uint64_t bits = s.total * 8;
   sha256_byte(s, 0x80);
   while (s.fill != 56) sha256_byte(s, 0);
@@ -71,7 +71,7 @@ BN_HD inline void sha256_final(Sha256& s, uint8_t* out) {
 
 // out[0..n) = expand_message_xmd(msg, dst, n), n <= 192 here (ell <= 6).  dst_len <= 255 (longer
 // DSTs are pre-hashed on the host, RFC 9380 5.3.3).
-BN_HD inline void expand_message_xmd(uint8_t* out, uint32_t n, const uint8_t* msg, size_t msg_len,
+BN_FUNC void expand_message_xmd(uint8_t* out, uint32_t n, const uint8_t* msg, size_t msg_len,
                                      const uint8_t* dst, uint32_t dst_len) {
   uint8_t b0[32], bi[32];
   Sha256 s;

@@ -64,7 +64,7 @@ BN_INL Fp2 fp2_add_mul_xi(const Fp2& x, const Fp2& y) {
 BN_INL Fp2 fp2_sub_mul_xi(const Fp2& x, const Fp2& y) {
   return {fp_lc3<1, -9, 1>(x.c0, y.c0, y.c1), fp_lc3<1, -1, -9>(x.c1, y.c0, y.c1)};
 }
-BN_HD inline Fp2 fp2_inv(const Fp2& a) {                                  // fp2.rs:161-166
+BN_FUNC Fp2 fp2_inv(const Fp2& a) {                                  // fp2.rs:161-166
   Fp2 n = fp2_norm(a);
   Fp t = fp_inv(fp_dot2(n.c0, n.c0, n.c1, n.c1));
   return {fp_mul(n.c0, t), fp_mul(fp_neg(n.c1), t)};
@@ -86,7 +86,7 @@ BN_INL Fp6 fp6_norm(const Fp6& a) { return {fp2_norm(a.c0), fp2_norm(a.c1), fp2_
 BN_INL Fp6 fp6_zero() { return {fp2_zero(), fp2_zero(), fp2_zero()}; }
 BN_INL Fp6 fp6_one() { return {fp2_one(), fp2_zero(), fp2_zero()}; }
 // inputs normalised ([~0, ~1] limbs); output normalised.  6 Fp2 products (fp6.rs:225-242 value).
-BN_HD inline Fp6 fp6_mul(const Fp6& a, const Fp6& b) {
+BN_FUNC Fp6 fp6_mul(const Fp6& a, const Fp6& b) {
   BN_CTX;
   Fp2 v0 = fp2_mul(a.c0, b.c0), v1 = fp2_mul(a.c1, b.c1), v2 = fp2_mul(a.c2, b.c2);
   Fp2 w0 = fp2_mul(fp2_sub(a.c1, a.c2), fp2_sub(b.c1, b.c2));
@@ -97,11 +97,11 @@ BN_HD inline Fp6 fp6_mul(const Fp6& a, const Fp6& b) {
   Fp2 t2 = fp2_sub(fp2_add(v0, v2), w2);        // a0 b2 + a2 b0
   return {fp2_add_mul_xi(v0, t0), fp2_add_mul_xi(t1, v2), fp2_norm(fp2_add(t2, v1))};
 }
-BN_HD inline Fp6 fp6_sqr(const Fp6& a) { return fp6_mul(a, a); }
+BN_FUNC Fp6 fp6_sqr(const Fp6& a) { return fp6_mul(a, a); }
 BN_INL Fp6 fp6_mul_v(const Fp6& a) { return {fp2_mul_xi(a.c2), a.c0, a.c1}; }      // fp6.rs:146-152
 BN_INL Fp6 fp6_mul_fp2(const Fp6& a, const Fp2& s) { return {fp2_mul(a.c0, s), fp2_mul(a.c1, s), fp2_mul(a.c2, s)}; }
 // a * (c0 + c1 v), fp6.rs:131-144 value; inputs and output normalised
-BN_HD inline Fp6 fp6_mul_by_01(const Fp6& a, const Fp2& c0, const Fp2& c1) {
+BN_FUNC Fp6 fp6_mul_by_01(const Fp6& a, const Fp2& c0, const Fp2& c1) {
   BN_CTX;
   Fp2 aa = fp2_mul(a.c0, c0), bb = fp2_mul(a.c1, c1);
   Fp2 cc = fp2_mul(a.c2, c1), dd = fp2_mul(a.c2, c0);
@@ -109,7 +109,7 @@ BN_HD inline Fp6 fp6_mul_by_01(const Fp6& a, const Fp2& c0, const Fp2& c1) {
   Fp2 t2 = fp2_sub(fp2_add(aa, bb), w);                       // a0 c1 + a1 c0
   return {fp2_add_mul_xi(aa, cc), fp2_norm(t2), fp2_norm(fp2_add(dd, bb))};
 }
-BN_HD inline Fp6 fp6_inv(const Fp6& a) {                       // fp6.rs:261-287 (denominator corrected)
+BN_FUNC Fp6 fp6_inv(const Fp6& a) {                       // fp6.rs:261-287 (denominator corrected)
   Fp2 s0 = fp2_sqr(a.c0), s1 = fp2_sqr(a.c1), s2 = fp2_sqr(a.c2);
   Fp2 m01 = fp2_mul(a.c0, a.c1), m02 = fp2_mul(a.c0, a.c2), m12 = fp2_mul(a.c1, a.c2);
   Fp2 c0 = fp2_sub_mul_xi(s0, m12);
@@ -128,12 +128,12 @@ BN_INL Fp6 fp6_add_mul_v(const Fp6& x, const Fp6& y) {
   BN_CTX;
   return {fp2_add_mul_xi(x.c0, y.c2), fp2_norm(fp2_add(x.c1, y.c0)), fp2_norm(fp2_add(x.c2, y.c1))};
 }
-BN_HD inline Fp12 fp12_mul(const Fp12& a, const Fp12& b) {     // fp12.rs:203-210 value
+BN_FUNC Fp12 fp12_mul(const Fp12& a, const Fp12& b) {     // fp12.rs:203-210 value
   Fp6 v0 = fp6_mul(a.c0, b.c0), v1 = fp6_mul(a.c1, b.c1);
   Fp6 w = fp6_mul(fp6_norm(fp6_sub(a.c0, a.c1)), fp6_norm(fp6_sub(b.c1, b.c0)));   // a0b1 + a1b0 - v0 - v1
   return {fp6_add_mul_v(v0, v1), fp6_norm(fp6_add(fp6_add(w, v0), v1))};
 }
-BN_HD inline Fp12 fp12_sqr(const Fp12& a) {                    // complex squaring, fp12.rs:170-180 value
+BN_FUNC Fp12 fp12_sqr(const Fp12& a) {                    // complex squaring, fp12.rs:170-180 value
   Fp6 ab = fp6_mul(a.c0, a.c1);
   Fp6 s1 = fp6_norm(fp6_add(a.c0, a.c1));
   Fp6 s2 = fp6_add_mul_v(a.c0, a.c1);
@@ -144,14 +144,14 @@ BN_HD inline Fp12 fp12_sqr(const Fp12& a) {                    // complex squari
   r.c1 = fp6_norm(fp6_add(ab, ab));
   return r;
 }
-BN_HD inline Fp12 fp12_inv(const Fp12& a) {                    // fp12.rs:212-219
+BN_FUNC Fp12 fp12_inv(const Fp12& a) {                    // fp12.rs:212-219
   Fp6 s0 = fp6_sqr(a.c0), s1 = fp6_sqr(a.c1);
   Fp6 d = {fp2_sub_mul_xi(s0.c0, s1.c2), fp2_norm(fp2_sub(s0.c1, s1.c0)), fp2_norm(fp2_sub(s0.c2, s1.c1))};
   Fp6 t = fp6_inv(d);
   return {fp6_mul(a.c0, t), fp6_norm(fp6_neg(fp6_mul(a.c1, t)))};
 }
 // f * (o0 + o3 w + o4 w^3): sparse multiply for D-type twist lines (E7).  13 Fp2 products.
-BN_HD inline Fp12 fp12_mul_by_034(const Fp12& f, const Fp2& o0, const Fp2& o3, const Fp2& o4) {
+BN_FUNC Fp12 fp12_mul_by_034(const Fp12& f, const Fp2& o0, const Fp2& o3, const Fp2& o4) {
   BN_CTX;
   Fp6 a = fp6_mul_fp2(f.c0, o0);
   Fp6 b = fp6_mul_by_01(f.c1, o3, o4);
@@ -162,7 +162,7 @@ BN_HD inline Fp12 fp12_mul_by_034(const Fp12& f, const Fp2& o0, const Fp2& o3, c
 }
 // Frobenius^k, k = 1..3: coefficient of w^i -> conj^k(.) * xi^(i (p^k-1)/6)   (E3 fixed)
 template <int K>
-BN_HD inline Fp12 fp12_frob(const Fp12& a) {
+BN_FUNC Fp12 fp12_frob(const Fp12& a) {
   BN_CTX;
   // tower slot -> w index: c0.c0=0 c1.c0=1 c0.c1=2 c1.c1=3 c0.c2=4 c1.c2=5
   const Fp2* s[6] = {&a.c0.c0, &a.c1.c0, &a.c0.c1, &a.c1.c1, &a.c0.c2, &a.c1.c2};
@@ -186,7 +186,7 @@ BN_INL void fp4_square(Fp2& c0, Fp2& c1, const Fp2& a, const Fp2& b) {      // p
   c1 = fp2_norm(fp2_dbl(ab));
 }
 // Granger-Scott squaring in the cyclotomic subgroup, pairings.rs:68-115 (valid with xi = 9+u)
-BN_HD inline Fp12 fp12_cyclotomic_sqr(const Fp12& f) {
+BN_FUNC Fp12 fp12_cyclotomic_sqr(const Fp12& f) {
   BN_CTX;
   Fp2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
   Fp2 t0, t1, t2, t3, t4, t5;

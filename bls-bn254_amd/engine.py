@@ -50,7 +50,8 @@ _ERR = {1: InvalidScalarBytes, 2: InvalidG1Bytes, 3: InvalidG2Bytes, 4: InvalidG
 
 
 def library_path():
-    return os.path.join(HERE, "libblsbn254_hip.so")
+    # BLSBN254_LIB selects another build of the SAME HIP library (A/B of compile options); never a fallback
+    return os.environ.get("BLSBN254_LIB") or os.path.join(HERE, "libblsbn254_hip.so")
 
 
 def load_library():

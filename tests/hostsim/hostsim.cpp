@@ -84,6 +84,14 @@ int hs_verify(const uint8_t* pk, const uint8_t* msg, size_t len, const uint8_t* 
   bool one = fp12_is_one(final_exponentiation(f));
   return (flags == (FLAG_SIG_OK | FLAG_PK_OK)) && sub && one;
 }
+// op counts of the two dominant phases in isolation (for the DESIGN.md instruction budget)
+void hs_miller_verify_only(const uint8_t* pk, const uint8_t* sig, const uint8_t* h64, uint8_t* ml_out) {
+  bool ok; G1A h = g1_decode(h64, ok);
+  uint8_t flags;
+  check_stats() = CheckStats();
+  Fp12 f = lane_miller_verify(pk, sig, h, bnc::ATE_NAF, bnc::ATE_NAF_LEN, BN_NEG_G2_LINE_TABLE, flags);
+  if (ml_out) fp12_to_be(ml_out, f);
+}
 void hs_stats(double* out) {
   CheckStats& s = check_stats();
   out[0] = s.worst_mul; out[1] = s.worst_dot; out[2] = s.worst_vb;
