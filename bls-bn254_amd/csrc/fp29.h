@@ -197,7 +197,7 @@ BN_INL Fp fp_lc3(const Fp& x1, const Fp& x2, const Fp& x3) {
          double m = a1 * mag(x1) + a2 * mag(x2) + a3 * mag(x3);            // |t| / L before the q*p term
          double vb = a1 * x1.vb + a2 * x2.vb + a3 * x3.vb;
          double tin = a1 * tmag(x1) + a2 * tmag(x2) + a3 * tmag(x3);       // |te| / L
-         if (tin >= 3.9) check_fail("fp_lc top-limb estimate overflows", tin);
+         if (tin >= 7.9) check_fail("fp_lc top-limb estimate: te * LC_QINV must fit 64 bits", tin);
          double mq = 0;
          if (REDUCE) { mq = vb + 1; m += mq; vb = 1.0 + (m + 4) / 3171406.0; }   // |q| <= vb + 1, |q p_i| <= mq L
          if (m >= 1.0e9) check_fail("fp_lc 64-bit limb sum", m);

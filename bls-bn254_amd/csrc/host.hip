@@ -34,6 +34,8 @@ struct blsbn254_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   DevBuf in_a, in_b, in_c, in_off, dst, h_ws, f_ws, f_ws2, flags, sub_ok, status, bitmap, out, scalars, misc;
+  DevBuf fe[6];          // final-exponentiation phase buffers (x, a, b, c, b2, d), 108 x n limbs each
+  DevBuf fe_slots;       // the ten named powers of the t -> t^x addition chain, 10 x 108 x n limbs
   bool profiling = false;
   std::map<std::string, ProfEntry> prof;
   std::string last_error;
@@ -95,6 +97,8 @@ void blsbn254_ctx_destroy(blsbn254_ctx* c) {
   for (auto& kv : c->prof) for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   DevBuf* bufs[] = {&c->in_a, &c->in_b, &c->in_c, &c->in_off, &c->dst, &c->h_ws, &c->f_ws, &c->f_ws2, &c->flags, &c->sub_ok, &c->status, &c->bitmap, &c->out, &c->scalars, &c->misc};
   for (DevBuf* b : bufs) b->release();
+  for (DevBuf& b : c->fe) b.release();
+  c->fe_slots.release();
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -183,6 +187,26 @@ static int read_status(blsbn254_ctx* c, const uint8_t* d_status, int idx, uint8_
   return 0;
 }
 
+// Final exponentiation of the n Fp12 values at f (limb-major, `stride`), in place for the easy part.
+//   mode 0: verify bitmap (flags / sub_ok / d_bitmap)   mode 1: Gt bytes   mode 3: single is_one flag (n == 1)
+static int run_final_exp(blsbn254_ctx* c, int32_t* f, size_t n, size_t stride, int mode, const uint8_t* flags, const uint8_t* sub_ok,
+                         uint8_t* d_bitmap, uint8_t* d_gt, int* d_is_one) {
+  for (DevBuf& b : c->fe) HIPCHK(c, b.reserve(stride * 108 * 4));
+  HIPCHK(c, c->fe_slots.reserve(stride * 108 * 4 * 10));
+  int32_t* S = (int32_t*)c->fe_slots.p;
+  int32_t *X = (int32_t*)c->fe[0].p, *A = (int32_t*)c->fe[1].p, *B = (int32_t*)c->fe[2].p, *C = (int32_t*)c->fe[3].p,
+          *B2 = (int32_t*)c->fe[4].p, *D = (int32_t*)c->fe[5].p;
+  LAUNCH(c, "fe_easy", k_fe_easy, n, (const int32_t*)f, f, n, stride);                       // t (in place)
+  LAUNCH(c, "fe_expx", k_fe_expx, n, (const int32_t*)f, X, S, n, stride);
+  LAUNCH(c, "fe_h1", k_fe_h1, n, (const int32_t*)X, A, B, n, stride);
+  LAUNCH(c, "fe_expx", k_fe_expx, n, (const int32_t*)B, X, S, n, stride);
+  LAUNCH(c, "fe_h2", k_fe_h2, n, (const int32_t*)X, (const int32_t*)B, C, B2, D, n, stride);
+  LAUNCH(c, "fe_expx", k_fe_expx, n, (const int32_t*)D, X, S, n, stride);
+  LAUNCH(c, "fe_h3", k_fe_h3, n, (const int32_t*)f, (const int32_t*)A, (const int32_t*)C, (const int32_t*)B2, (const int32_t*)X, n, stride,
+         flags, sub_ok, d_bitmap, d_gt, d_is_one, mode);
+  return 0;
+}
+
 // ---------------- pairing / Miller loop / final exponentiation
 static int miller_to_ws(blsbn254_ctx* c, const uint8_t* d_g1, const uint8_t* d_g2, size_t n) {
   HIPCHK(c, c->f_ws.reserve(n * 108 * 4));
@@ -205,7 +229,8 @@ int blsbn254_pairing_batch_dev(blsbn254_ctx* c, const uint8_t* d_g1, const uint8
   HIPCHK(c, hipSetDevice(c->device));
   int rc = miller_to_ws(c, d_g1, d_g2, n);
   if (rc) return rc;
-  LAUNCH(c, "final_exp", k_final_exp, n, (const int32_t*)c->f_ws.p, n, n, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr, d_gt, 1);
+  rc = run_final_exp(c, (int32_t*)c->f_ws.p, n, n, 1, nullptr, nullptr, nullptr, d_gt, nullptr);
+  if (rc) return rc;
   if (d_status) HIPCHK(c, hipMemcpyAsync(d_status, c->status.p, n, hipMemcpyDeviceToDevice, c->stream));
   return 0;
 }
@@ -282,7 +307,8 @@ int blsbn254_final_exponentiation(blsbn254_ctx* c, const uint8_t* ml, size_t n, 
   int bad; int rc = first_bad(c, (const uint8_t*)c->status.p, n, 1, 1, &bad);
   if (rc) return rc;
   if (bad >= 0) return BLSBN254_ERR_GT;
-  LAUNCH(c, "final_exp", k_final_exp, n, (const int32_t*)c->f_ws.p, n, n, (const uint8_t*)nullptr, (const uint8_t*)nullptr, (uint8_t*)nullptr, (uint8_t*)c->out.p, 2);
+  rc = run_final_exp(c, (int32_t*)c->f_ws.p, n, n, 1, nullptr, nullptr, nullptr, (uint8_t*)c->out.p, nullptr);
+  if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(gt, c->out.p, 384 * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
@@ -354,8 +380,7 @@ int blsbn254_verify_batch_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8
   LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, d_msgs, d_off, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, (uint8_t*)nullptr, 0);
   LAUNCH(c, "g2_check", k_g2_check, n, d_pks, n, (uint8_t*)c->sub_ok.p, (uint8_t*)nullptr);
   LAUNCH(c, "miller_verify", k_miller_verify, n, d_pks, d_sigs, (const int32_t*)c->h_ws.p, n, (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
-  LAUNCH(c, "final_exp", k_final_exp, n, (const int32_t*)c->f_ws.p, n, n, (const uint8_t*)c->flags.p, (const uint8_t*)c->sub_ok.p, d_bitmap, (uint8_t*)nullptr, 0);
-  return 0;
+  return run_final_exp(c, (int32_t*)c->f_ws.p, n, n, 0, (const uint8_t*)c->flags.p, (const uint8_t*)c->sub_ok.p, d_bitmap, nullptr, nullptr);
 }
 int blsbn254_verify_batch(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs,
                           size_t n, const uint8_t* dst, size_t dst_len, uint8_t* bm) {
@@ -420,7 +445,8 @@ int blsbn254_aggregate_verify(blsbn254_ctx* c, const uint8_t* pks, const uint8_t
     LAUNCH(c, "fp12_mul_pairs", k_fp12_mul_pairs, mo, (const int32_t*)a, cnt, sa, b, mo);
     std::swap(a, b); sa = mo; cnt = mo;
   }
-  LAUNCH(c, "final_exp_is_one", k_final_exp_is_one, 1, (const int32_t*)a, sa, d_flags + 1);
+  rc = run_final_exp(c, a, 1, sa, 3, nullptr, nullptr, nullptr, nullptr, d_flags + 1);
+  if (rc) return rc;
   int h_flags[2]; uint8_t sig_st, sig_on_curve;
   HIPCHK(c, hipMemcpyAsync(h_flags, d_flags, 8, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(&sig_st, c->status.p, 1, hipMemcpyDeviceToHost, c->stream));

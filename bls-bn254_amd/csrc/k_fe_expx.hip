@@ -1,0 +1,14 @@
+// k_fe_expx.hip -- t -> t^x in the cyclotomic subgroup (x = 0x44e992b44a6909f1) by the addition chain of
+// pairing.h (62 Granger-Scott squarings + 17 multiplications), fully inlined.  The running value r lives in
+// registers; the ten named powers of the chain are parked in a limb-major HBM workspace (10 x 432 B per
+// tuple, each re-read at most four times: ~10 KB per tuple against ~0.45 M VALU ops) so that r plus the
+// temporaries of one product fit the 512 registers of a 1-wave-per-SIMD kernel.
+#include "lane_ops.h"
+#include "kernels.h"
+using namespace bn;
+
+BN_KERNEL k_fe_expx(const int32_t* in, int32_t* out, int32_t* slots, size_t n, size_t stride) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  fp12_store_limbs(out + i, stride, cyclotomic_exp_x_chain(fp12_load_limbs(in + i, stride), slots + i, stride));
+}

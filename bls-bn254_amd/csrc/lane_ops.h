@@ -78,8 +78,9 @@ BN_FUNC Fp12 lane_miller_1(const uint8_t* g1, const uint8_t* g2, const int8_t* n
   return f;
 }
 // verify: f = ML(sig, -G2gen) * ML(H, pk); flags = FLAG_SIG_OK | FLAG_PK_OK when decodable, on curve, non-identity
+// park != nullptr: loop invariants and T are parked there (LDS on the device, 144 dwords per lane)
 BN_FUNC Fp12 lane_miller_verify(const uint8_t* pk_b, const uint8_t* sig_b, const G1A& h, const int8_t* naf, int naf_len,
-                                     const int32_t (*table)[54], uint8_t& flags) {
+                                     const int32_t (*table)[54], uint8_t& flags, int32_t* park = nullptr, size_t park_stride = 1) {
   bool oks, okp;
   G1A sig = g1_decode(sig_b, oks);
   G2A pk = g2_decode(pk_b, okp);
@@ -91,6 +92,7 @@ BN_FUNC Fp12 lane_miller_verify(const uint8_t* pk_b, const uint8_t* sig_b, const
   G1A gp; gp.x = fp_one(); gp.y = fp_norm(fp_add(fp_one(), fp_one())); gp.inf = false;
   sig.x = fp_select(sig_ok, sig.x, gp.x); sig.y = fp_select(sig_ok, sig.y, gp.y);
   pk.x = fp2_select(pk_ok, pk.x, fp2_const(bnc::G2_GEN_X)); pk.y = fp2_select(pk_ok, pk.y, fp2_const(bnc::G2_GEN_Y));
+  if (park) return miller_loop_verify_mem(sig, h, pk, naf, naf_len, table, park, park_stride);
   return miller_loop_verify(sig, h, pk, naf, naf_len, table);
 }
 

@@ -129,6 +129,63 @@ BN_FUNC Fp12 miller_loop_verify(const G1A& sig, const G1A& h, const G2A& pk, con
   return f;
 }
 
+// Same loop with the loop invariants (sig, H, pk, -pk.y) and the running point T parked in memory (LDS in
+// k_miller_verify): 144 dwords per lane.  f and the temporaries of the current product keep the registers.
+// Park slots (one slot = one Fp = 9 limbs): 0 sig.x, 1 sig.y, 2 h.x, 3 h.y, 4-5 pk.x, 6-7 pk.y, 8-9 -pk.y,
+// 10-15 T = (x, y, z).
+BN_INL G2J g2j_load_mem(const int32_t* p, size_t st) {
+  return {fp2_load_mem(p + 90 * st, st), fp2_load_mem(p + 108 * st, st), fp2_load_mem(p + 126 * st, st)};
+}
+BN_INL void g2j_store_mem(int32_t* p, size_t st, const G2J& t) {
+  fp2_store_mem(p + 90 * st, st, t.x); fp2_store_mem(p + 108 * st, st, t.y); fp2_store_mem(p + 126 * st, st, t.z);
+}
+BN_FUNC Fp12 miller_loop_verify_mem(const G1A& sig, const G1A& h, const G2A& pk, const int8_t* naf, int naf_len,
+                                    const int32_t (*table)[54], int32_t* park, size_t st) {
+  fp_store_mem(park, st, fp_norm(sig.x)); fp_store_mem(park + 9 * st, st, fp_norm(sig.y));
+  fp_store_mem(park + 18 * st, st, fp_norm(h.x)); fp_store_mem(park + 27 * st, st, fp_norm(h.y));
+  fp2_store_mem(park + 36 * st, st, fp2_norm(pk.x)); fp2_store_mem(park + 54 * st, st, fp2_norm(pk.y));
+  fp2_store_mem(park + 72 * st, st, fp2_norm(fp2_neg(pk.y)));
+  { G2J T0 = {fp2_norm(pk.x), fp2_norm(pk.y), fp2_one()}; g2j_store_mem(park, st, T0); }
+  BN_MEM_FENCE;
+  Fp12 f = fp12_one();
+  int ti = 0;
+  for (int j = naf_len - 2; j >= 0; --j) {
+    f = fp12_sqr(f);
+    f = ell(f, line_from_table(table[ti++]), fp_load_mem(park, st), fp_load_mem(park + 9 * st, st));
+    BN_MEM_FENCE;
+    Line l;
+    { G2J T = g2j_load_mem(park, st); l = doubling_step(T); g2j_store_mem(park, st, T); }
+    BN_MEM_FENCE;
+    f = ell(f, l, fp_load_mem(park + 18 * st, st), fp_load_mem(park + 27 * st, st));
+    BN_MEM_FENCE;
+    int d = naf[j];
+    if (d != 0) {
+      f = ell(f, line_from_table(table[ti++]), fp_load_mem(park, st), fp_load_mem(park + 9 * st, st));
+      BN_MEM_FENCE;
+      { G2J T = g2j_load_mem(park, st);
+        l = addition_step(T, fp2_load_mem(park + 36 * st, st), fp2_load_mem(park + (d > 0 ? 54 : 72) * st, st));
+        g2j_store_mem(park, st, T); }
+      BN_MEM_FENCE;
+      f = ell(f, l, fp_load_mem(park + 18 * st, st), fp_load_mem(park + 27 * st, st));
+      BN_MEM_FENCE;
+    }
+  }
+  Fp2 g2 = fp2_const(bnc::GAMMA1[1]), g3 = fp2_const(bnc::GAMMA1[2]);
+  Fp2 q1x = fp2_mul(fp2_norm(fp2_conj(fp2_load_mem(park + 36 * st, st))), g2);
+  Fp2 q1y = fp2_mul(fp2_norm(fp2_conj(fp2_load_mem(park + 54 * st, st))), g3);
+  Fp2 q2x = fp2_mul(fp2_norm(fp2_conj(q1x)), g2);
+  Fp2 q2y = fp2_norm(fp2_neg(fp2_mul(fp2_norm(fp2_conj(q1y)), g3)));
+  Line l;
+  f = ell(f, line_from_table(table[ti++]), fp_load_mem(park, st), fp_load_mem(park + 9 * st, st));
+  { G2J T = g2j_load_mem(park, st); l = addition_step(T, q1x, q1y); g2j_store_mem(park, st, T); }
+  BN_MEM_FENCE;
+  f = ell(f, l, fp_load_mem(park + 18 * st, st), fp_load_mem(park + 27 * st, st));
+  f = ell(f, line_from_table(table[ti++]), fp_load_mem(park, st), fp_load_mem(park + 9 * st, st));
+  { G2J T = g2j_load_mem(park, st); l = addition_step(T, q2x, q2y); }
+  f = ell(f, l, fp_load_mem(park + 18 * st, st), fp_load_mem(park + 27 * st, st));
+  return f;
+}
+
 // f^x for the BN parameter x (63 bits, x > 0), f in the cyclotomic subgroup
 BN_FUNC Fp12 cyclotomic_exp_x(const Fp12& f) {
   BN_CTX;
@@ -139,30 +196,80 @@ BN_FUNC Fp12 cyclotomic_exp_x(const Fp12& f) {
   }
   return r;
 }
-BN_FUNC Fp12 final_exponentiation(const Fp12& f) {
-  BN_CTX;
-  // easy part: f^((p^6-1)(p^2+1))
+// Final exponentiation f -> f^((p^12-1)/r * 2x(6x^2+3x+1)), split into phases so that each phase can be
+// its own register-resident kernel (k_finalexp.hip); final_exponentiation() is their composition.
+//   easy:  t  = f^((p^6-1)(p^2+1))
+//   hard:  t^(l0 + l1 p + l2 p^2 + l3 p^3), Fuentes-Castaneda et al. arrangement with three t -> t^x
+//          exponentiations (cyclotomic_exp_x) separated by the small steps h1, h2, h3.
+// f^x with f parked in memory (LDS in k_fe_expx): r stays in registers, f's halves are loaded per product
+BN_FUNC Fp12 cyclotomic_exp_x_mem(const Fp12& f, int32_t* park, size_t stride) {
+  fp12_store_mem(park, stride, f);
+  BN_MEM_FENCE;
+  Fp12 r = f;
+  for (int i = 61; i >= 0; --i) {
+    r = fp12_cyclotomic_sqr(r);
+    if ((bnc::BN_X >> i) & 1) r = fp12_mul_mem(r, park, stride);
+  }
+  return r;
+}
+// f^x by the addition chain
+//   _10 = 2*1, _100 = 2*_10, _1000 = 2*_100, _10000 = 2*_1000, _10001 = 1 + _10000, _10011 = _10 + _10001,
+//   _10100 = 1 + _10011, _11001 = _1000 + _10001, _100010 = 2*_10001, _100111 = _10011 + _10100, _101001 = _10 + _100111,
+//   i27 = (_100010 << 6 + _100 + _11001) << 7 + _11001,  i44 = (i27 << 8 + _101001 + _10) << 6 + _10001,
+//   i70 = ((i44 << 8 + _101001) << 6 + _101001) << 10,   x = (_100111 + i70) << 6 + _101001 + _1000
+// = 62 cyclotomic squarings + 17 multiplications (binary: 27).  Run as a small uniform interpreter (one
+// inlined squaring and one inlined multiply-by-memory-operand in the loop body): the ten named powers
+// live in `slots` (limb-major memory, 10 x 108 limbs per lane) and are read back one Fp6 half at a time.
+struct ExpxOp { int8_t load, sq, mul, store; };
+BN_FUNC Fp12 cyclotomic_exp_x_chain(const Fp12& f, int32_t* slots, size_t st) {
+  const ExpxOp prog[22] = {{-1, 1, -1, 1}, {-1, 1, -1, 2}, {-1, 1, -1, 3}, {-1, 1, 0, 4}, {-1, 0, 1, 5}, {-1, 0, 0, 6}, {3, 0, 4, 7},
+                           {5, 0, 6, 8}, {-1, 0, 1, 9}, {4, 1, -1, -1}, {-1, 6, 2, -1}, {-1, 0, 7, -1}, {-1, 7, 7, -1}, {-1, 8, 9, -1},
+                           {-1, 0, 1, -1}, {-1, 6, 4, -1}, {-1, 8, 9, -1}, {-1, 6, 9, -1}, {-1, 10, -1, -1}, {-1, 0, 8, -1}, {-1, 6, 9, -1},
+                           {-1, 0, 3, -1}};
+  const size_t slot = 108 * st;
+  fp12_store_mem(slots, st, f);
+  BN_MEM_FENCE;
+  Fp12 r = f;
+  for (int k = 0; k < 22; ++k) {
+    const ExpxOp op = prog[k];
+    if (op.load >= 0) r = fp12_load_mem(slots + op.load * slot, st);
+    for (int q = 0; q < op.sq; ++q) r = fp12_cyclotomic_sqr(r);
+    if (op.mul >= 0) r = fp12_mul_mem(r, slots + op.mul * slot, st);
+    if (op.store >= 0) { fp12_store_mem(slots + op.store * slot, st, r); BN_MEM_FENCE; }
+  }
+  return r;
+}
+BN_FUNC Fp12 fe_easy(const Fp12& f) {
   Fp12 t = fp12_mul(fp12_conj(f), fp12_inv(f));
-  t = fp12_mul(fp12_frob<2>(t), t);
-  // hard part: t^(l0 + l1 p + l2 p^2 + l3 p^3), Fuentes-Castaneda et al. arrangement
-  Fp12 a = fp12_conj(cyclotomic_exp_x(t));                 // t^-x
-  a = fp12_cyclotomic_sqr(a);                              // t^-2x
-  Fp12 b = fp12_cyclotomic_sqr(a);                         // t^-4x
-  b = fp12_mul(a, b);                                      // t^-6x
-  Fp12 c = fp12_conj(cyclotomic_exp_x(b));                 // t^(6x^2)
-  Fp12 d = fp12_conj(b);                                   // t^(6x)
-  b = fp12_mul(c, d);                                      // t^(6x^2+6x)
-  d = fp12_cyclotomic_sqr(c);                              // t^(12x^2)
-  Fp12 e = cyclotomic_exp_x(d);                            // t^(12x^3)
-  e = fp12_mul(b, e);                                      // l2
-  d = fp12_mul(a, e);                                      // l1
-  a = fp12_mul(c, e);                                      // t^(12x^3+12x^2+6x)
-  c = fp12_mul(t, a);                                      // l0
-  a = fp12_mul(c, fp12_frob<1>(d));
-  a = fp12_mul(a, fp12_frob<2>(e));
-  c = fp12_mul(fp12_conj(t), d);                           // l3
-  a = fp12_mul(a, fp12_frob<3>(c));
-  return a;
+  return fp12_mul(fp12_frob<2>(t), t);
+}
+// x0 = t^x  ->  a = t^-2x, b = t^-6x
+BN_FUNC void fe_h1(const Fp12& x0, Fp12& a, Fp12& b) {
+  a = fp12_cyclotomic_sqr(fp12_conj(x0));
+  Fp12 a2 = fp12_cyclotomic_sqr(a);                        // t^-4x
+  b = fp12_mul(a, a2);
+}
+// x0 = b^x = t^(-6x^2)  ->  c = t^(6x^2), b2 = t^(6x^2+6x), d2 = t^(12x^2)
+BN_FUNC void fe_h2(const Fp12& x0, const Fp12& b, Fp12& c, Fp12& b2, Fp12& d2) {
+  c = fp12_conj(x0);
+  b2 = fp12_mul(c, fp12_conj(b));
+  d2 = fp12_cyclotomic_sqr(c);
+}
+// x0 = d2^x = t^(12x^3)  ->  result
+BN_FUNC Fp12 fe_h3(const Fp12& t, const Fp12& a, const Fp12& c, const Fp12& b2, const Fp12& x0) {
+  Fp12 e = fp12_mul(b2, x0);                               // l2 = 12x^3+6x^2+6x
+  Fp12 d = fp12_mul(a, e);                                 // l1 = 12x^3+6x^2+4x
+  Fp12 l0 = fp12_mul(t, fp12_mul(c, e));                   // l0 = 12x^3+12x^2+6x+1
+  Fp12 r = fp12_mul(l0, fp12_frob<1>(d));
+  r = fp12_mul(r, fp12_frob<2>(e));
+  Fp12 l3 = fp12_mul(fp12_conj(t), d);                     // l3 = 12x^3+6x^2+4x-1
+  return fp12_mul(r, fp12_frob<3>(l3));
+}
+BN_FUNC Fp12 final_exponentiation(const Fp12& f) {
+  Fp12 t = fe_easy(f), a, b, c, b2, d2;
+  fe_h1(cyclotomic_exp_x(t), a, b);
+  fe_h2(cyclotomic_exp_x(b), b, c, b2, d2);
+  return fe_h3(t, a, c, b2, cyclotomic_exp_x(d2));
 }
 
 // Gt byte layout (Gt::to_repr / from_repr, pairings.rs:499-579): c0.c0.c0, c0.c0.c1, c0.c1.c0, ...

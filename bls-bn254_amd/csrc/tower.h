@@ -133,6 +133,56 @@ BN_FUNC Fp12 fp12_mul(const Fp12& a, const Fp12& b) {     // fp12.rs:203-210 val
   Fp6 w = fp6_mul(fp6_norm(fp6_sub(a.c0, a.c1)), fp6_norm(fp6_sub(b.c1, b.c0)));   // a0b1 + a1b0 - v0 - v1
   return {fp6_add_mul_v(v0, v1), fp6_norm(fp6_add(fp6_add(w, v0), v1))};
 }
+// ---- operands parked in memory (LDS on the device): limb k of Fp element e at p[(9*e + k) * stride].
+// With stride = workgroup size the 64 lanes of a wave hit 64 consecutive dwords: conflict-free
+// ds_read_b32.  BN_MEM_FENCE stops the compiler from keeping a loaded operand alive in registers across
+// phases (that is the whole point of parking it).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BN_MEM_FENCE asm volatile("" ::: "memory")
+#else
+#define BN_MEM_FENCE do { } while (0)
+#endif
+#ifdef BN_CHECK
+}  // namespace bn
+#include <map>
+namespace bn {
+// check mode: the proven bounds of a parked value travel with its address
+struct ParkTrk { double lo, hi, tlo, thi, vb; };
+inline std::map<const int32_t*, ParkTrk>& park_trk() { static std::map<const int32_t*, ParkTrk> m; return m; }
+#endif
+BN_INL Fp fp_load_mem(const int32_t* p, size_t stride) {
+  Fp r;
+  BN_UNROLL for (int k = 0; k < NL; ++k) r.l[k] = p[(size_t)k * stride];
+  BN_TRK(auto it = park_trk().find(p); if (it == park_trk().end()) check_fail("fp_load_mem of an address never stored", 0);
+         set_trk(r, it->second.lo, it->second.hi, it->second.tlo, it->second.thi, it->second.vb);)
+  return r;
+}
+BN_INL void fp_store_mem(int32_t* p, size_t stride, const Fp& a) {
+  BN_TRK(if (a.lo < -1e-6 || a.hi > 1.0 + 1e-6) check_fail("fp_store_mem needs a normalised value", mag(a));
+         park_trk()[p] = ParkTrk{a.lo, a.hi, a.tlo, a.thi, a.vb};)
+  BN_UNROLL for (int k = 0; k < NL; ++k) p[(size_t)k * stride] = a.l[k];
+}
+BN_INL Fp2 fp2_load_mem(const int32_t* p, size_t stride) { return {fp_load_mem(p, stride), fp_load_mem(p + 9 * stride, stride)}; }
+BN_INL Fp6 fp6_load_mem(const int32_t* p, size_t stride) {
+  return {fp2_load_mem(p, stride), fp2_load_mem(p + 18 * stride, stride), fp2_load_mem(p + 36 * stride, stride)};
+}
+BN_INL void fp2_store_mem(int32_t* p, size_t stride, const Fp2& a) { fp_store_mem(p, stride, a.c0); fp_store_mem(p + 9 * stride, stride, a.c1); }
+BN_INL void fp6_store_mem(int32_t* p, size_t stride, const Fp6& a) {
+  fp2_store_mem(p, stride, a.c0); fp2_store_mem(p + 18 * stride, stride, a.c1); fp2_store_mem(p + 36 * stride, stride, a.c2);
+}
+BN_INL void fp12_store_mem(int32_t* p, size_t stride, const Fp12& a) { fp6_store_mem(p, stride, a.c0); fp6_store_mem(p + 54 * stride, stride, a.c1); }
+BN_INL Fp12 fp12_load_mem(const int32_t* p, size_t stride) { return {fp6_load_mem(p, stride), fp6_load_mem(p + 54 * stride, stride)}; }
+// a * b with b parked in memory: its Fp6 halves are loaded when needed, never held across phases
+BN_FUNC Fp12 fp12_mul_mem(const Fp12& a, const int32_t* b, size_t stride) {
+  Fp6 v0, v1, w;
+  { Fp6 b0 = fp6_load_mem(b, stride); v0 = fp6_mul(a.c0, b0); }
+  BN_MEM_FENCE;
+  { Fp6 b1 = fp6_load_mem(b + 54 * stride, stride); v1 = fp6_mul(a.c1, b1); }
+  BN_MEM_FENCE;
+  { Fp6 b0 = fp6_load_mem(b, stride), b1 = fp6_load_mem(b + 54 * stride, stride);
+    w = fp6_mul(fp6_norm(fp6_sub(a.c0, a.c1)), fp6_norm(fp6_sub(b1, b0))); }
+  return {fp6_add_mul_v(v0, v1), fp6_norm(fp6_add(fp6_add(w, v0), v1))};
+}
 BN_FUNC Fp12 fp12_sqr(const Fp12& a) {                    // complex squaring, fp12.rs:170-180 value
   Fp6 ab = fp6_mul(a.c0, a.c1);
   Fp6 s1 = fp6_norm(fp6_add(a.c0, a.c1));
@@ -182,8 +232,8 @@ BN_FUNC Fp12 fp12_frob(const Fp12& a) {
 BN_INL void fp4_square(Fp2& c0, Fp2& c1, const Fp2& a, const Fp2& b) {      // pairings.rs:52-63
   Fp2 t0 = fp2_sqr(a), t1 = fp2_sqr(b);
   c0 = fp2_add_mul_xi(t0, t1);
-  Fp2 ab = fp2_mul(a, b);                                       // (a+b)^2 - a^2 - b^2 = 2ab
-  c1 = fp2_norm(fp2_dbl(ab));
+  Fp2 s = fp2_sqr(fp2_norm(fp2_add(a, b)));                     // three squarings (2 x 162 MADs each) instead of a
+  c1 = fp2_norm(fp2_sub(fp2_sub(s, t0), t1));                   // product (486 MADs): 2ab = (a+b)^2 - a^2 - b^2
 }
 // Granger-Scott squaring in the cyclotomic subgroup, pairings.rs:68-115 (valid with xi = 9+u)
 BN_FUNC Fp12 fp12_cyclotomic_sqr(const Fp12& f) {

@@ -47,6 +47,15 @@ void hs_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* out) {
   Fp12 f = lane_miller_1(g1, g2, bnc::ATE_NAF, bnc::ATE_NAF_LEN, st);
   fp12_to_be(out, final_exponentiation(f));
 }
+int hs_expx_mem_matches(const uint8_t* in) {       // cyclotomic_exp_x_mem == cyclotomic_exp_x on a cyclotomic element
+  bool ok;
+  Fp12 t = fe_easy(fp12_from_be(in, ok));
+  static int32_t park[108 * 10];
+  Fp12 a = cyclotomic_exp_x(t), b = cyclotomic_exp_x_mem(t, park, 1), c = cyclotomic_exp_x_chain(t, park, 1), d = c;
+  uint8_t ba[384], bb[384], bc[384], bd[384];
+  fp12_to_be(ba, a); fp12_to_be(bb, b); fp12_to_be(bc, c); fp12_to_be(bd, d);
+  return std::memcmp(ba, bb, 384) == 0 && std::memcmp(ba, bc, 384) == 0 && std::memcmp(ba, bd, 384) == 0;
+}
 void hs_fp12_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
   bool o1, o2;
   Fp12 x = fp12_from_be(a, o1), y = fp12_from_be(b, o2);

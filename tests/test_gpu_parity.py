@@ -226,3 +226,43 @@ def test_device_resident_entry_points(eng, oracle, M):
     eng.verify_batch_dev(t_pk.data_ptr(), t_ms.data_ptr(), t_off.data_ptr(), t_sg.data_ptr(), n, t_bm.data_ptr(), dst)
     eng.synchronize()
     assert bytes(t_bm.cpu().numpy()) == synth.bitmap_of(exp)
+
+
+def test_aggregate_verify_1m(eng, oracle, pyref, M):
+    """BASELINE configs[2]: one aggregated G1 signature over 1 048 576 (pk_i, msg_i).  64 signed tuples
+    are tiled (the oracle cannot sign a million); the aggregate of the tiled set is (n/64) * sum_64, so
+    the expected answer is known: valid, and invalid after corrupting one message."""
+    dst = M.DEFAULT_DST
+    n, uniq = 1 << 20, 64
+    sks = [synth.sk_of(k) for k in range(8)]
+    pk_pool = [oracle.sk_to_pk(s) for s in sks]
+    base = [(pk_pool[i % 8], synth.msg_of(i)) for i in range(uniq)]
+    sig64 = oracle.aggregate_sigs(b"".join(oracle.sign(sks[i % 8], base[i][1], dst) for i in range(uniq)), uniq)
+    agg = oracle.g1_mul(sig64, n // uniq)
+    pks = b"".join(b[0] for b in base) * (n // uniq)
+    msgs = [b[1] for b in base] * (n // uniq)
+    assert eng.aggregate_verify(pks, msgs, agg, dst) is True
+    msgs[777777] = b"corrupted"
+    assert eng.aggregate_verify(pks, msgs, agg, dst) is False
+
+
+def test_threshold_1000_of_2000(eng, oracle, pyref, M):
+    """BASELINE configs[4]: combine 1000 partial signatures (ids drawn from 1..2000) and verify under f(0)*G2."""
+    dst = M.DEFAULT_DST
+    rnd = random.Random(2000)
+    t, total = 1000, 2000
+    coeffs = [rnd.randrange(1, pyref.R) for _ in range(t)]
+    ids = rnd.sample(range(1, total + 1), t)
+
+    def f(x):
+        acc = 0
+        for c in reversed(coeffs):
+            acc = (acc * x + c) % pyref.R
+        return acc
+    msg = b"threshold-1000-of-2000"
+    h = oracle.hash_to_g1_batch([msg], dst)
+    parts = b"".join(oracle.g1_mul(h, f(i)) for i in ids)
+    idb = b"".join(i.to_bytes(32, "big") for i in ids)
+    sig = eng.threshold_combine(idb, parts, t)
+    assert sig == oracle.sign(coeffs[0], msg, dst)
+    assert eng.verify_batch(oracle.sk_to_pk(coeffs[0]), [msg], sig, dst) == b"\x01"

@@ -60,6 +60,7 @@ def test_pairing_path_bit_exact_and_bounded(hs, oracle, pyref, kats):
         p, q = oracle.g1_mul(G1, rnd.randrange(1, pyref.R)), oracle.g2_mul(G2, rnd.randrange(1, pyref.R))
         hs.hs_miller1(p, q, ml, ctypes.byref(st)); assert ml.raw == oracle.miller_loop_batch(p, q, 1)
         hs.hs_pairing(p, q, gt); assert gt.raw == oracle.pairing_batch(p, q, 1)
+    assert hs.hs_expx_mem_matches(oracle.miller_loop_batch(G1, G2, 1)) == 1       # LDS-parked operand variant
     ident = bytes(32) + (1).to_bytes(32, "big")
     hs.hs_miller1(ident, G2, ml, ctypes.byref(st))
     assert st.value == 7 and ml.raw == (1).to_bytes(32, "big") + bytes(352)
