@@ -1,0 +1,22 @@
+// k_miller_verify.hip -- the dominant kernel: f = ML(sig, -G2gen) * ML(H(msg), pk), first pair from the fixed line table.
+// Compiled with the tower functions force-inlined (-DBN_FORCE_INLINE) so that the register allocator sees
+// the whole loop body and f / T stay in the 512 VGPR+AGPR of a 1-wave-per-SIMD kernel instead of
+// round-tripping through scratch (r01 profile: 270 KB of scratch traffic per tuple with outlined calls,
+// 41.9 -> 32.5 ms once inlined).  One kernel per translation unit: they compile in parallel.
+#define BN_WANT_LINE_TABLE
+#define BN_LINE_TABLE_QUAL static __device__ const
+#include "lane_ops.h"
+#include "kernels.h"
+using namespace bn;
+
+static __device__ const int8_t d_ate_naf[bnc::ATE_NAF_LEN] = BN_ATE_NAF_INIT;
+
+BN_KERNEL k_miller_verify(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n, int32_t* f_ws, uint8_t* flags) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  G1A h; h.x = load_fp(h_ws + i, n); h.y = load_fp(h_ws + 9 * n + i, n); h.inf = false;
+  uint8_t fl;
+  Fp12 f = lane_miller_verify(pks + 128 * i, sigs + 64 * i, h, d_ate_naf, bnc::ATE_NAF_LEN, BN_NEG_G2_LINE_TABLE, fl);
+  fp12_store_limbs(f_ws + i, n, f);
+  flags[i] = fl;
+}
