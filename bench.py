@@ -31,8 +31,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=N_PER_GPU, help="tuples per GPU")
+    ap.add_argument("--tuples-per-gpu", dest="n", type=int, default=N_PER_GPU, help="tuples per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--all-on-device0", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
 
     import numpy as np
@@ -41,10 +43,13 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.all_on_device0 else int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 

@@ -19,16 +19,6 @@ __device__ inline void store_g1p(int32_t* ws, size_t stride, const G1P& p) {
 __device__ inline G1P load_g1p(const int32_t* ws, size_t stride) {
   return {load_fp(ws, stride), load_fp(ws + 9 * stride, stride), load_fp(ws + 18 * stride, stride)};
 }
-BN_KERNEL k_hash_to_g1(const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
-                       int32_t* h_ws, uint8_t* out_bytes, int mode) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint8_t* m = msgs + off[i];
-  size_t len = (size_t)(off[i + 1] - off[i]);
-  G1A h = mode == 2 ? lane_encode_to_g1(m, len, dst, dst_len) : lane_hash_to_g1(m, len, dst, dst_len);
-  if (mode == 0) { store_fp(h_ws + i, n, h.x); store_fp(h_ws + 9 * n + i, n, h.y); }
-  else g1_encode(out_bytes + 64 * i, h);
-}
 BN_KERNEL k_hash_to_g2(const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
                        uint8_t* out_bytes, int ro) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -39,12 +29,6 @@ BN_KERNEL k_g1_check(const uint8_t* g1, size_t n, uint8_t* bitmap) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool ok = i < n ? lane_g1_check(g1 + 64 * i) : false;
   write_ballot(bitmap, n, i, ok);
-}
-BN_KERNEL k_g2_check(const uint8_t* g2, size_t n, uint8_t* ok_bytes, uint8_t* bitmap) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  bool ok = i < n ? lane_g2_check(g2 + 128 * i) : false;
-  if (ok_bytes && i < n) ok_bytes[i] = ok;
-  if (bitmap) write_ballot(bitmap, n, i, ok);
 }
 BN_KERNEL k_fp12_from_bytes(const uint8_t* in, size_t n, int32_t* f_ws, uint8_t* status) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,6 +89,9 @@ BN_KERNEL k_lagrange(const uint8_t* ids, size_t t, uint8_t* scalars, uint8_t* st
   fr_to_be(scalars + 32 * i, lam);
   status[i] = ok ? 1 : 0;
 }
+// VALU roofline probe: 8 independent 64-bit multiply-accumulate chains per lane (compiler-selected
+// v_mad_u64_u32, no shared VCC), every CU busy at 4 waves per SIMD.  The denominator of bench.py's
+// roofline.frac is measured in the same run (BASELINE.md section 3 "same-run rule").
 __global__ void __launch_bounds__(256) k_valu_peak(uint32_t* out, uint32_t seed, int iters) {
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t a = seed * 2654435761u + tid, b = (seed ^ 0x9e3779b9u) + tid * 7u;
@@ -113,15 +100,15 @@ __global__ void __launch_bounds__(256) k_valu_peak(uint32_t* out, uint32_t seed,
   for (int i = 0; i < iters; ++i) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      uint64_t r;
-      asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(acc[c]) : "vcc");
-      acc[c] = r;
+      acc[c] = (uint64_t)a * (uint32_t)(b + c) + acc[c];
+      asm("" : "+v"(acc[c]));
     }
   }
   uint64_t s = 0;
   for (int c = 0; c < 8; ++c) s ^= acc[c];
   out[tid] = (uint32_t)s ^ (uint32_t)(s >> 32);
 }
+// status reductions
 __global__ void k_status_reduce(const uint8_t* status, size_t n, uint8_t want_mask, uint8_t want_val, int* first_bad) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && (status[i] & want_mask) != want_val) atomicMin(first_bad, (int)(i > 0x7ffffffe ? 0x7ffffffe : i));
