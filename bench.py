@@ -127,6 +127,14 @@ def main():
         achieved = mil_mads / (mil_ms * 1e-3) / 1e12
         peak = eng.valu_peak() / 1e12
         kern = {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in prof.items()}
+        # HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes of this build
+        traffic, traffic_note = None, "no PMC profile committed"
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath) and n == N_PER_GPU:
+            tj = json.load(open(tpath))
+            if "k_miller_verify" in tj.get("kernels", {}):
+                traffic = tj["kernels"]["k_miller_verify"]["hbm_bytes_per_launch"]
+                traffic_note = "PMC FETCH_SIZE/WRITE_SIZE of the same kernel at the same batch size (profiles/r01_traffic.json): register-spill scratch traffic, ~%d KB per tuple vs ~1.4 KB algorithmic" % (traffic // n // 1024)
         out = {
             "metric": "BN254 pairings/sec (= BLS verifies/sec)", "value": round(value, 1), "unit": "verifies/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -136,10 +144,10 @@ def main():
                                    % (n, "" if world == 1 else " x %d ranks, bitmap all-reduce over RCCL" % world),
                        "tuples_per_gpu": n, "tuples_total": n_total},
             "roofline": {"bound": "valu", "kernel": "k_miller_verify", "achieved": round(achieved, 4), "peak": round(peak, 3),
-                         "unit": "T int-MAD/s", "frac": round(achieved / peak, 4), "traffic": None,
+                         "unit": "T int-MAD/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
                          "note": "achieved = (%d+%d) Fp-mul x %d MAD x %d tuples / %.3f ms (HIP events on the engine stream); "
-                                 "peak = v_mad_u64_u32 rate measured in this run; the path is VALU-bound, HBM traffic is "
-                                 "~1.4 KB/verify (see profiles/)" % (core[0], core[1], FP_MUL_MADS, n, mil_ms)},
+                                 "peak = v_mad_u64_u32 rate measured in this run (blsbn254_valu_peak); the path is bound by VALU integer "
+                                 "issue, not HBM (algorithmic traffic ~1.4 KB/verify) and not MFMA" % (core[0], core[1], FP_MUL_MADS, n, mil_ms)},
             "kernel_ms": kern,
             "algorithmic_fp_mul_per_verify": {"miller_variable_pair": core[0], "miller_fixed_pair_lines": core[1], "final_exp": core[2]},
         }
