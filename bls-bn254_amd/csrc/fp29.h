@@ -38,6 +38,7 @@
 #else
 #define BN_FUNC BN_HD inline
 #endif
+
 #define BN_UNROLL _Pragma("unroll")
 
 #ifdef BN_CHECK
