@@ -129,6 +129,58 @@ BN_FUNC Fp12 miller_loop_verify(const G1A& sig, const G1A& h, const G2A& pk, con
   return f;
 }
 
+// Variant for k_miller_verify: the loop invariants are NOT kept in registers.  They sit in a limb-major
+// workspace `inv` (slots of 9 limbs: 0 sig.x, 1 sig.y, 2 h.x, 3 h.y, 4-5 pk.x, 6-7 pk.y) and are re-loaded
+// where they are used (once per line); BN_OPAQUE hides the pointer from the optimiser in every iteration
+// so the loads are not hoisted back out of the loop.  Frees 90 of the 256 architectural VGPRs for f, T and
+// the temporaries of the current product.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BN_OPAQUE(p) asm volatile("" : "+v"(p))
+#else
+#define BN_OPAQUE(p) do { } while (0)
+#endif
+BN_FUNC Fp12 miller_loop_verify_ws(const int32_t* inv, size_t st, const int8_t* naf, int naf_len, const int32_t (*table)[54]) {
+  Fp12 f = fp12_one();
+  G2J T = {fp2_load_mem(inv + 36 * st, st), fp2_load_mem(inv + 54 * st, st), fp2_one()};
+  int ti = 0;
+  for (int j = naf_len - 2; j >= 0; --j) {
+    const int32_t* p = inv;
+    f = fp12_sqr(f);
+    BN_OPAQUE(p);
+    f = ell(f, line_from_table(table[ti++]), fp_load_mem(p, st), fp_load_mem(p + 9 * st, st));
+    Line l = doubling_step(T);
+    BN_OPAQUE(p);
+    f = ell(f, l, fp_load_mem(p + 18 * st, st), fp_load_mem(p + 27 * st, st));
+    int d = naf[j];
+    if (d != 0) {
+      BN_OPAQUE(p);
+      f = ell(f, line_from_table(table[ti++]), fp_load_mem(p, st), fp_load_mem(p + 9 * st, st));
+      BN_OPAQUE(p);
+      Fp2 qy = fp2_load_mem(p + 54 * st, st);
+      Fp2 nqy = fp2_norm(fp2_neg(qy));
+      l = addition_step(T, fp2_load_mem(p + 36 * st, st), fp2_select(d > 0, qy, nqy));
+      BN_OPAQUE(p);
+      f = ell(f, l, fp_load_mem(p + 18 * st, st), fp_load_mem(p + 27 * st, st));
+    }
+  }
+  const int32_t* p = inv;
+  BN_OPAQUE(p);
+  Fp2 g2 = fp2_const(bnc::GAMMA1[1]), g3 = fp2_const(bnc::GAMMA1[2]);
+  Fp2 q1x = fp2_mul(fp2_norm(fp2_conj(fp2_load_mem(p + 36 * st, st))), g2);
+  Fp2 q1y = fp2_mul(fp2_norm(fp2_conj(fp2_load_mem(p + 54 * st, st))), g3);
+  Fp2 q2x = fp2_mul(fp2_norm(fp2_conj(q1x)), g2);
+  Fp2 q2y = fp2_norm(fp2_neg(fp2_mul(fp2_norm(fp2_conj(q1y)), g3)));
+  f = ell(f, line_from_table(table[ti++]), fp_load_mem(p, st), fp_load_mem(p + 9 * st, st));
+  Line l = addition_step(T, q1x, q1y);
+  BN_OPAQUE(p);
+  f = ell(f, l, fp_load_mem(p + 18 * st, st), fp_load_mem(p + 27 * st, st));
+  f = ell(f, line_from_table(table[ti++]), fp_load_mem(p, st), fp_load_mem(p + 9 * st, st));
+  l = addition_step(T, q2x, q2y);
+  BN_OPAQUE(p);
+  f = ell(f, l, fp_load_mem(p + 18 * st, st), fp_load_mem(p + 27 * st, st));
+  return f;
+}
+
 // Same loop with the loop invariants (sig, H, pk, -pk.y) and the running point T parked in memory (LDS in
 // k_miller_verify): 144 dwords per lane.  f and the temporaries of the current product keep the registers.
 // Park slots (one slot = one Fp = 9 limbs): 0 sig.x, 1 sig.y, 2 h.x, 3 h.y, 4-5 pk.x, 6-7 pk.y, 8-9 -pk.y,
