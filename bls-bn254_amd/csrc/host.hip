@@ -515,4 +515,40 @@ int blsbn254_threshold_combine(blsbn254_ctx* c, const uint8_t* ids, const uint8_
   return g1_sum_to_bytes(c, t, out_sig);
 }
 
+// ---------------- signing side
+int blsbn254_sign_batch(blsbn254_ctx* c, const uint8_t* sks, const uint8_t* msgs, const uint64_t* off, size_t n,
+                        const uint8_t* dst, size_t dst_len, uint8_t* sigs_out) {
+  if (!c || !off || (n && (!sks || !sigs_out)) || (dst_len && !dst)) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
+  if (rc) return rc;
+  rc = stage_msgs(c, msgs, off, n);
+  if (rc) return rc;
+  HIPCHK(c, c->in_a.reserve(32 * n)); HIPCHK(c, c->out.reserve(64 * n)); HIPCHK(c, c->status.reserve(n));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, sks, 32 * n, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "sign", k_sign, n, (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl,
+         (uint8_t*)c->out.p, (uint8_t*)c->status.p);
+  int bad; rc = first_bad(c, (const uint8_t*)c->status.p, n, 1, 1, &bad);
+  if (rc) return rc;
+  if (bad >= 0) return BLSBN254_ERR_SCALAR;
+  HIPCHK(c, hipMemcpyAsync(sigs_out, c->out.p, 64 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int blsbn254_sk_to_pk_batch(blsbn254_ctx* c, const uint8_t* sks, size_t n, uint8_t* pks_out) {
+  if (!c || (n && (!sks || !pks_out))) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->in_a.reserve(32 * n)); HIPCHK(c, c->out.reserve(128 * n)); HIPCHK(c, c->status.reserve(n));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, sks, 32 * n, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "sk_to_pk", k_sk_to_pk, n, (const uint8_t*)c->in_a.p, n, (uint8_t*)c->out.p, (uint8_t*)c->status.p);
+  int bad; int rc = first_bad(c, (const uint8_t*)c->status.p, n, 1, 1, &bad);
+  if (rc) return rc;
+  if (bad >= 0) return BLSBN254_ERR_SCALAR;
+  HIPCHK(c, hipMemcpyAsync(pks_out, c->out.p, 128 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 }  // extern "C"

@@ -12,11 +12,18 @@ using namespace bn;
 static __device__ const int8_t d_ate_naf[bnc::ATE_NAF_LEN] = BN_ATE_NAF_INIT;
 
 BN_KERNEL k_miller_verify(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n, int32_t* f_ws, uint8_t* flags, int32_t* inv_ws) {
+#ifdef BN_PARK_T
+  __shared__ int32_t tpark[54 * 256];      // running point T, [limb][lane], parked between line steps
+#endif
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   G1A h; h.x = load_fp(h_ws + i, n); h.y = load_fp(h_ws + 9 * n + i, n); h.inf = false;
   uint8_t fl;
-  Fp12 f = lane_miller_verify_ws(pks + 128 * i, sigs + 64 * i, h, d_ate_naf, bnc::ATE_NAF_LEN, BN_NEG_G2_LINE_TABLE, fl, inv_ws + i, n);
+  Fp12 f = lane_miller_verify_ws(pks + 128 * i, sigs + 64 * i, h, d_ate_naf, bnc::ATE_NAF_LEN, BN_NEG_G2_LINE_TABLE, fl, inv_ws + i, n
+#ifdef BN_PARK_T
+                                 , tpark + threadIdx.x, 256
+#endif
+                                 );
   fp12_store_limbs(f_ws + i, n, f);
   flags[i] = fl;
 }

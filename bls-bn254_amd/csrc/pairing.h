@@ -139,16 +139,23 @@ BN_FUNC Fp12 miller_loop_verify(const G1A& sig, const G1A& h, const G2A& pk, con
 #else
 #define BN_OPAQUE(p) do { } while (0)
 #endif
-BN_FUNC Fp12 miller_loop_verify_ws(const int32_t* inv, size_t st, const int8_t* naf, int naf_len, const int32_t (*table)[54]) {
+// tpark != nullptr: the running point T (54 limbs) is parked there (LDS, [limb][lane]) between line steps.
+BN_INL void t_store(int32_t* tp, size_t ts, const G2J& T) { fp2_store_mem(tp, ts, T.x); fp2_store_mem(tp + 18 * ts, ts, T.y); fp2_store_mem(tp + 36 * ts, ts, T.z); }
+BN_INL G2J t_load(const int32_t* tp, size_t ts) { return {fp2_load_mem(tp, ts), fp2_load_mem(tp + 18 * ts, ts), fp2_load_mem(tp + 36 * ts, ts)}; }
+BN_FUNC Fp12 miller_loop_verify_ws(const int32_t* inv, size_t st, const int8_t* naf, int naf_len, const int32_t (*table)[54],
+                                   int32_t* tpark = nullptr, size_t ts = 1) {
   Fp12 f = fp12_one();
   G2J T = {fp2_load_mem(inv + 36 * st, st), fp2_load_mem(inv + 54 * st, st), fp2_one()};
+  if (tpark) { t_store(tpark, ts, T); BN_MEM_FENCE; }
   int ti = 0;
   for (int j = naf_len - 2; j >= 0; --j) {
     const int32_t* p = inv;
     f = fp12_sqr(f);
     BN_OPAQUE(p);
     f = ell(f, line_from_table(table[ti++]), fp_load_mem(p, st), fp_load_mem(p + 9 * st, st));
-    Line l = doubling_step(T);
+    Line l;
+    if (tpark) { BN_MEM_FENCE; G2J Tl = t_load(tpark, ts); l = doubling_step(Tl); t_store(tpark, ts, Tl); BN_MEM_FENCE; }
+    else l = doubling_step(T);
     BN_OPAQUE(p);
     f = ell(f, l, fp_load_mem(p + 18 * st, st), fp_load_mem(p + 27 * st, st));
     int d = naf[j];
@@ -158,7 +165,8 @@ BN_FUNC Fp12 miller_loop_verify_ws(const int32_t* inv, size_t st, const int8_t* 
       BN_OPAQUE(p);
       Fp2 qy = fp2_load_mem(p + 54 * st, st);
       Fp2 nqy = fp2_norm(fp2_neg(qy));
-      l = addition_step(T, fp2_load_mem(p + 36 * st, st), fp2_select(d > 0, qy, nqy));
+      if (tpark) { BN_MEM_FENCE; G2J Tl = t_load(tpark, ts); l = addition_step(Tl, fp2_load_mem(p + 36 * st, st), fp2_select(d > 0, qy, nqy)); t_store(tpark, ts, Tl); BN_MEM_FENCE; }
+      else l = addition_step(T, fp2_load_mem(p + 36 * st, st), fp2_select(d > 0, qy, nqy));
       BN_OPAQUE(p);
       f = ell(f, l, fp_load_mem(p + 18 * st, st), fp_load_mem(p + 27 * st, st));
     }
@@ -171,6 +179,7 @@ BN_FUNC Fp12 miller_loop_verify_ws(const int32_t* inv, size_t st, const int8_t* 
   Fp2 q2x = fp2_mul(fp2_norm(fp2_conj(q1x)), g2);
   Fp2 q2y = fp2_norm(fp2_neg(fp2_mul(fp2_norm(fp2_conj(q1y)), g3)));
   f = ell(f, line_from_table(table[ti++]), fp_load_mem(p, st), fp_load_mem(p + 9 * st, st));
+  if (tpark) { BN_MEM_FENCE; T = t_load(tpark, ts); }
   Line l = addition_step(T, q1x, q1y);
   BN_OPAQUE(p);
   f = ell(f, l, fp_load_mem(p + 18 * st, st), fp_load_mem(p + 27 * st, st));

@@ -210,6 +210,20 @@ class Engine:
         self._chk(self._lib.blsbn254_threshold_combine(self._ctx, pa, ps, ctypes.c_size_t(t), po))
         return o.tobytes()
 
+    # ---- signing side (also used to generate large synthetic batches)
+    def sign_batch(self, sks, msgs, dst=DEFAULT_DST):
+        n = len(msgs)
+        data, off = pack_messages(msgs)
+        k, pk = _inbuf(sks, 32 * n); m, pm = _inbuf(data); d, pd = _inbuf(dst); o, po = _outbuf(64 * n)
+        self._chk(self._lib.blsbn254_sign_batch(self._ctx, pk, pm, off.ctypes.data_as(_u64p), ctypes.c_size_t(n), pd,
+                                                ctypes.c_size_t(len(dst)), po))
+        return o[:64 * n].tobytes()
+
+    def sk_to_pk_batch(self, sks, n):
+        k, pk = _inbuf(sks, 32 * n); o, po = _outbuf(128 * n)
+        self._chk(self._lib.blsbn254_sk_to_pk_batch(self._ctx, pk, ctypes.c_size_t(n), po))
+        return o[:128 * n].tobytes()
+
     # ---- device-resident variants (raw device pointers, e.g. torch tensor .data_ptr())
     def verify_batch_dev(self, d_pks, d_msgs, d_off, d_sigs, n, d_bitmap, dst=DEFAULT_DST):
         d, pd = _inbuf(dst)

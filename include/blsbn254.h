@@ -98,6 +98,15 @@ int blsbn254_aggregate_sigs(blsbn254_ctx* ctx, const uint8_t* sigs, size_t n, ui
  * (Mul<Scalar> g1.rs:518-534 + Sum; Fr arithmetic scalar.rs:523-548) */
 int blsbn254_threshold_combine(blsbn254_ctx* ctx, const uint8_t* ids, const uint8_t* partial_sigs, size_t t, uint8_t out_sig[64]);
 
+/* ---- signing side (also used to generate large synthetic batches) ----------- */
+/* sig_i = [sk_i] H(msg_i): G1Projective::hash (g1.rs:910-919) + Mul<Scalar> (g1.rs:518-534, :821-841).
+ * sks = n x 32 B big-endian, each < r (else BLSBN254_ERR_SCALAR).  Not constant time (the reference's
+ * ladder is; a verification engine handles public data -- do not use with production secrets). */
+int blsbn254_sign_batch(blsbn254_ctx* ctx, const uint8_t* sks, const uint8_t* msgs, const uint64_t* off, size_t n,
+                        const uint8_t* dst, size_t dst_len, uint8_t* sigs_out);
+/* pk_i = [sk_i] G2gen: Mul<Scalar> for G2Projective (g2.rs:866-886) */
+int blsbn254_sk_to_pk_batch(blsbn254_ctx* ctx, const uint8_t* sks, size_t n, uint8_t* pks_out);
+
 /* ---- device-resident variants (plumbing for callers that already hold the batch in HBM) ----- */
 /* All d_* pointers are device pointers on ctx's GPU.  Work is enqueued on ctx's stream and is
  * complete after blsbn254_ctx_synchronize().  d_valid_bitmap needs ceil(n/8) bytes. */

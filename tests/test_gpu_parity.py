@@ -266,3 +266,23 @@ def test_threshold_1000_of_2000(eng, oracle, pyref, M):
     sig = eng.threshold_combine(idb, parts, t)
     assert sig == oracle.sign(coeffs[0], msg, dst)
     assert eng.verify_batch(oracle.sk_to_pk(coeffs[0]), [msg], sig, dst) == b"\x01"
+
+
+def test_sign_and_keygen_kernels(eng, oracle, pyref, M):
+    """[sk]H(msg) and [sk]G2gen on the GPU, bit-exact vs the oracle."""
+    dst = M.DEFAULT_DST
+    rnd = random.Random(77)
+    n = 70
+    sks = [rnd.randrange(1, pyref.R) for _ in range(n - 3)] + [1, 2, pyref.R - 1]
+    msgs = [bytes(rnd.randrange(256) for _ in range(rnd.randrange(0, 50))) for _ in range(n)]
+    skb = b"".join(s.to_bytes(32, "big") for s in sks)
+    sigs = eng.sign_batch(skb, msgs, dst)
+    pks = eng.sk_to_pk_batch(skb, n)
+    for i in range(n):
+        assert sigs[64 * i:64 * i + 64] == oracle.sign(sks[i], msgs[i], dst)
+        assert pks[128 * i:128 * i + 128] == oracle.sk_to_pk(sks[i])
+    assert eng.verify_batch(pks, msgs, sigs, dst) == synth.bitmap_of([True] * n)
+    with pytest.raises(M.InvalidScalarBytes):
+        eng.sign_batch(pyref.R.to_bytes(32, "big"), [b"m"], dst)
+    with pytest.raises(M.InvalidScalarBytes):
+        eng.sk_to_pk_batch(b"\xff" * 32, 1)
