@@ -81,8 +81,7 @@ BN_FUNC Fp12 lane_miller_1(const uint8_t* g1, const uint8_t* g2, const int8_t* n
 // Variant that first writes the validated operands to the limb-major workspace `inv` (72 limbs per tuple) and
 // runs the loop that re-loads them per use (miller_loop_verify_ws).
 BN_FUNC Fp12 lane_miller_verify_ws(const uint8_t* pk_b, const uint8_t* sig_b, const G1A& h, const int8_t* naf, int naf_len,
-                                   const int32_t (*table)[54], uint8_t& flags, int32_t* inv, size_t st,
-                                   int32_t* tpark = nullptr, size_t ts = 1) {
+                                   const int32_t (*table)[54], uint8_t& flags, int32_t* inv, size_t st) {
   bool oks, okp;
   G1A sig = g1_decode(sig_b, oks);
   G2A pk = g2_decode(pk_b, okp);
@@ -95,11 +94,10 @@ BN_FUNC Fp12 lane_miller_verify_ws(const uint8_t* pk_b, const uint8_t* sig_b, co
   fp2_store_mem(inv + 36 * st, st, fp2_norm(fp2_select(pk_ok, pk.x, fp2_const(bnc::G2_GEN_X))));
   fp2_store_mem(inv + 54 * st, st, fp2_norm(fp2_select(pk_ok, pk.y, fp2_const(bnc::G2_GEN_Y))));
   BN_MEM_FENCE;
-  return miller_loop_verify_ws(inv, st, naf, naf_len, table, tpark, ts);
+  return miller_loop_verify_ws(inv, st, naf, naf_len, table);
 }
-// park != nullptr: loop invariants and T are parked there (LDS on the device, 144 dwords per lane)
 BN_FUNC Fp12 lane_miller_verify(const uint8_t* pk_b, const uint8_t* sig_b, const G1A& h, const int8_t* naf, int naf_len,
-                                     const int32_t (*table)[54], uint8_t& flags, int32_t* park = nullptr, size_t park_stride = 1) {
+                                     const int32_t (*table)[54], uint8_t& flags) {
   bool oks, okp;
   G1A sig = g1_decode(sig_b, oks);
   G2A pk = g2_decode(pk_b, okp);
@@ -111,7 +109,6 @@ BN_FUNC Fp12 lane_miller_verify(const uint8_t* pk_b, const uint8_t* sig_b, const
   G1A gp; gp.x = fp_one(); gp.y = fp_norm(fp_add(fp_one(), fp_one())); gp.inf = false;
   sig.x = fp_select(sig_ok, sig.x, gp.x); sig.y = fp_select(sig_ok, sig.y, gp.y);
   pk.x = fp2_select(pk_ok, pk.x, fp2_const(bnc::G2_GEN_X)); pk.y = fp2_select(pk_ok, pk.y, fp2_const(bnc::G2_GEN_Y));
-  if (park) return miller_loop_verify_mem(sig, h, pk, naf, naf_len, table, park, park_stride);
   return miller_loop_verify(sig, h, pk, naf, naf_len, table);
 }
 

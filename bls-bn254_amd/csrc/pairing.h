@@ -139,23 +139,16 @@ BN_FUNC Fp12 miller_loop_verify(const G1A& sig, const G1A& h, const G2A& pk, con
 #else
 #define BN_OPAQUE(p) do { } while (0)
 #endif
-// tpark != nullptr: the running point T (54 limbs) is parked there (LDS, [limb][lane]) between line steps.
-BN_INL void t_store(int32_t* tp, size_t ts, const G2J& T) { fp2_store_mem(tp, ts, T.x); fp2_store_mem(tp + 18 * ts, ts, T.y); fp2_store_mem(tp + 36 * ts, ts, T.z); }
-BN_INL G2J t_load(const int32_t* tp, size_t ts) { return {fp2_load_mem(tp, ts), fp2_load_mem(tp + 18 * ts, ts), fp2_load_mem(tp + 36 * ts, ts)}; }
-BN_FUNC Fp12 miller_loop_verify_ws(const int32_t* inv, size_t st, const int8_t* naf, int naf_len, const int32_t (*table)[54],
-                                   int32_t* tpark = nullptr, size_t ts = 1) {
+BN_FUNC Fp12 miller_loop_verify_ws(const int32_t* inv, size_t st, const int8_t* naf, int naf_len, const int32_t (*table)[54]) {
   Fp12 f = fp12_one();
   G2J T = {fp2_load_mem(inv + 36 * st, st), fp2_load_mem(inv + 54 * st, st), fp2_one()};
-  if (tpark) { t_store(tpark, ts, T); BN_MEM_FENCE; }
   int ti = 0;
   for (int j = naf_len - 2; j >= 0; --j) {
     const int32_t* p = inv;
     f = fp12_sqr(f);
     BN_OPAQUE(p);
     f = ell(f, line_from_table(table[ti++]), fp_load_mem(p, st), fp_load_mem(p + 9 * st, st));
-    Line l;
-    if (tpark) { BN_MEM_FENCE; G2J Tl = t_load(tpark, ts); l = doubling_step(Tl); t_store(tpark, ts, Tl); BN_MEM_FENCE; }
-    else l = doubling_step(T);
+    Line l = doubling_step(T);
     BN_OPAQUE(p);
     f = ell(f, l, fp_load_mem(p + 18 * st, st), fp_load_mem(p + 27 * st, st));
     int d = naf[j];
@@ -165,8 +158,7 @@ BN_FUNC Fp12 miller_loop_verify_ws(const int32_t* inv, size_t st, const int8_t* 
       BN_OPAQUE(p);
       Fp2 qy = fp2_load_mem(p + 54 * st, st);
       Fp2 nqy = fp2_norm(fp2_neg(qy));
-      if (tpark) { BN_MEM_FENCE; G2J Tl = t_load(tpark, ts); l = addition_step(Tl, fp2_load_mem(p + 36 * st, st), fp2_select(d > 0, qy, nqy)); t_store(tpark, ts, Tl); BN_MEM_FENCE; }
-      else l = addition_step(T, fp2_load_mem(p + 36 * st, st), fp2_select(d > 0, qy, nqy));
+      l = addition_step(T, fp2_load_mem(p + 36 * st, st), fp2_select(d > 0, qy, nqy));
       BN_OPAQUE(p);
       f = ell(f, l, fp_load_mem(p + 18 * st, st), fp_load_mem(p + 27 * st, st));
     }
@@ -179,7 +171,6 @@ BN_FUNC Fp12 miller_loop_verify_ws(const int32_t* inv, size_t st, const int8_t* 
   Fp2 q2x = fp2_mul(fp2_norm(fp2_conj(q1x)), g2);
   Fp2 q2y = fp2_norm(fp2_neg(fp2_mul(fp2_norm(fp2_conj(q1y)), g3)));
   f = ell(f, line_from_table(table[ti++]), fp_load_mem(p, st), fp_load_mem(p + 9 * st, st));
-  if (tpark) { BN_MEM_FENCE; T = t_load(tpark, ts); }
   Line l = addition_step(T, q1x, q1y);
   BN_OPAQUE(p);
   f = ell(f, l, fp_load_mem(p + 18 * st, st), fp_load_mem(p + 27 * st, st));
@@ -187,63 +178,6 @@ BN_FUNC Fp12 miller_loop_verify_ws(const int32_t* inv, size_t st, const int8_t* 
   l = addition_step(T, q2x, q2y);
   BN_OPAQUE(p);
   f = ell(f, l, fp_load_mem(p + 18 * st, st), fp_load_mem(p + 27 * st, st));
-  return f;
-}
-
-// Same loop with the loop invariants (sig, H, pk, -pk.y) and the running point T parked in memory (LDS in
-// k_miller_verify): 144 dwords per lane.  f and the temporaries of the current product keep the registers.
-// Park slots (one slot = one Fp = 9 limbs): 0 sig.x, 1 sig.y, 2 h.x, 3 h.y, 4-5 pk.x, 6-7 pk.y, 8-9 -pk.y,
-// 10-15 T = (x, y, z).
-BN_INL G2J g2j_load_mem(const int32_t* p, size_t st) {
-  return {fp2_load_mem(p + 90 * st, st), fp2_load_mem(p + 108 * st, st), fp2_load_mem(p + 126 * st, st)};
-}
-BN_INL void g2j_store_mem(int32_t* p, size_t st, const G2J& t) {
-  fp2_store_mem(p + 90 * st, st, t.x); fp2_store_mem(p + 108 * st, st, t.y); fp2_store_mem(p + 126 * st, st, t.z);
-}
-BN_FUNC Fp12 miller_loop_verify_mem(const G1A& sig, const G1A& h, const G2A& pk, const int8_t* naf, int naf_len,
-                                    const int32_t (*table)[54], int32_t* park, size_t st) {
-  fp_store_mem(park, st, fp_norm(sig.x)); fp_store_mem(park + 9 * st, st, fp_norm(sig.y));
-  fp_store_mem(park + 18 * st, st, fp_norm(h.x)); fp_store_mem(park + 27 * st, st, fp_norm(h.y));
-  fp2_store_mem(park + 36 * st, st, fp2_norm(pk.x)); fp2_store_mem(park + 54 * st, st, fp2_norm(pk.y));
-  fp2_store_mem(park + 72 * st, st, fp2_norm(fp2_neg(pk.y)));
-  { G2J T0 = {fp2_norm(pk.x), fp2_norm(pk.y), fp2_one()}; g2j_store_mem(park, st, T0); }
-  BN_MEM_FENCE;
-  Fp12 f = fp12_one();
-  int ti = 0;
-  for (int j = naf_len - 2; j >= 0; --j) {
-    f = fp12_sqr(f);
-    f = ell(f, line_from_table(table[ti++]), fp_load_mem(park, st), fp_load_mem(park + 9 * st, st));
-    BN_MEM_FENCE;
-    Line l;
-    { G2J T = g2j_load_mem(park, st); l = doubling_step(T); g2j_store_mem(park, st, T); }
-    BN_MEM_FENCE;
-    f = ell(f, l, fp_load_mem(park + 18 * st, st), fp_load_mem(park + 27 * st, st));
-    BN_MEM_FENCE;
-    int d = naf[j];
-    if (d != 0) {
-      f = ell(f, line_from_table(table[ti++]), fp_load_mem(park, st), fp_load_mem(park + 9 * st, st));
-      BN_MEM_FENCE;
-      { G2J T = g2j_load_mem(park, st);
-        l = addition_step(T, fp2_load_mem(park + 36 * st, st), fp2_load_mem(park + (d > 0 ? 54 : 72) * st, st));
-        g2j_store_mem(park, st, T); }
-      BN_MEM_FENCE;
-      f = ell(f, l, fp_load_mem(park + 18 * st, st), fp_load_mem(park + 27 * st, st));
-      BN_MEM_FENCE;
-    }
-  }
-  Fp2 g2 = fp2_const(bnc::GAMMA1[1]), g3 = fp2_const(bnc::GAMMA1[2]);
-  Fp2 q1x = fp2_mul(fp2_norm(fp2_conj(fp2_load_mem(park + 36 * st, st))), g2);
-  Fp2 q1y = fp2_mul(fp2_norm(fp2_conj(fp2_load_mem(park + 54 * st, st))), g3);
-  Fp2 q2x = fp2_mul(fp2_norm(fp2_conj(q1x)), g2);
-  Fp2 q2y = fp2_norm(fp2_neg(fp2_mul(fp2_norm(fp2_conj(q1y)), g3)));
-  Line l;
-  f = ell(f, line_from_table(table[ti++]), fp_load_mem(park, st), fp_load_mem(park + 9 * st, st));
-  { G2J T = g2j_load_mem(park, st); l = addition_step(T, q1x, q1y); g2j_store_mem(park, st, T); }
-  BN_MEM_FENCE;
-  f = ell(f, l, fp_load_mem(park + 18 * st, st), fp_load_mem(park + 27 * st, st));
-  f = ell(f, line_from_table(table[ti++]), fp_load_mem(park, st), fp_load_mem(park + 9 * st, st));
-  { G2J T = g2j_load_mem(park, st); l = addition_step(T, q2x, q2y); }
-  f = ell(f, l, fp_load_mem(park + 18 * st, st), fp_load_mem(park + 27 * st, st));
   return f;
 }
 
@@ -262,17 +196,6 @@ BN_FUNC Fp12 cyclotomic_exp_x(const Fp12& f) {
 //   easy:  t  = f^((p^6-1)(p^2+1))
 //   hard:  t^(l0 + l1 p + l2 p^2 + l3 p^3), Fuentes-Castaneda et al. arrangement with three t -> t^x
 //          exponentiations (cyclotomic_exp_x) separated by the small steps h1, h2, h3.
-// f^x with f parked in memory (LDS in k_fe_expx): r stays in registers, f's halves are loaded per product
-BN_FUNC Fp12 cyclotomic_exp_x_mem(const Fp12& f, int32_t* park, size_t stride) {
-  fp12_store_mem(park, stride, f);
-  BN_MEM_FENCE;
-  Fp12 r = f;
-  for (int i = 61; i >= 0; --i) {
-    r = fp12_cyclotomic_sqr(r);
-    if ((bnc::BN_X >> i) & 1) r = fp12_mul_mem(r, park, stride);
-  }
-  return r;
-}
 // f^x by the addition chain
 //   _10 = 2*1, _100 = 2*_10, _1000 = 2*_100, _10000 = 2*_1000, _10001 = 1 + _10000, _10011 = _10 + _10001,
 //   _10100 = 1 + _10011, _11001 = _1000 + _10001, _100010 = 2*_10001, _100111 = _10011 + _10100, _101001 = _10 + _100111,

@@ -47,14 +47,14 @@ void hs_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* out) {
   Fp12 f = lane_miller_1(g1, g2, bnc::ATE_NAF, bnc::ATE_NAF_LEN, st);
   fp12_to_be(out, final_exponentiation(f));
 }
-int hs_expx_mem_matches(const uint8_t* in) {       // cyclotomic_exp_x_mem == cyclotomic_exp_x on a cyclotomic element
+int hs_expx_chain_matches(const uint8_t* in) {      // addition chain == binary ladder on a cyclotomic element
   bool ok;
   Fp12 t = fe_easy(fp12_from_be(in, ok));
-  static int32_t park[108 * 10];
-  Fp12 a = cyclotomic_exp_x(t), b = cyclotomic_exp_x_mem(t, park, 1), c = cyclotomic_exp_x_chain(t, park, 1), d = c;
-  uint8_t ba[384], bb[384], bc[384], bd[384];
-  fp12_to_be(ba, a); fp12_to_be(bb, b); fp12_to_be(bc, c); fp12_to_be(bd, d);
-  return std::memcmp(ba, bb, 384) == 0 && std::memcmp(ba, bc, 384) == 0 && std::memcmp(ba, bd, 384) == 0;
+  static int32_t slots[108 * 10];
+  Fp12 a = cyclotomic_exp_x(t), c = cyclotomic_exp_x_chain(t, slots, 1);
+  uint8_t ba[384], bc[384];
+  fp12_to_be(ba, a); fp12_to_be(bc, c);
+  return std::memcmp(ba, bc, 384) == 0;
 }
 void hs_fp12_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
   bool o1, o2;
@@ -100,6 +100,15 @@ void hs_miller_verify_only(const uint8_t* pk, const uint8_t* sig, const uint8_t*
   check_stats() = CheckStats();
   Fp12 f = lane_miller_verify(pk, sig, h, bnc::ATE_NAF, bnc::ATE_NAF_LEN, BN_NEG_G2_LINE_TABLE, flags);
   if (ml_out) fp12_to_be(ml_out, f);
+}
+// the workspace-reload variant of the verify Miller loop (what k_miller_verify runs)
+void hs_miller_verify_ws(const uint8_t* pk, const uint8_t* sig, const uint8_t* h64, uint8_t* ml_out, int* flags_out) {
+  bool ok; G1A h = g1_decode(h64, ok);
+  uint8_t flags;
+  static int32_t inv[72];
+  Fp12 f = lane_miller_verify_ws(pk, sig, h, bnc::ATE_NAF, bnc::ATE_NAF_LEN, BN_NEG_G2_LINE_TABLE, flags, inv, 1);
+  fp12_to_be(ml_out, f);
+  *flags_out = flags;
 }
 void hs_stats(double* out) {
   CheckStats& s = check_stats();

@@ -286,3 +286,34 @@ def test_sign_and_keygen_kernels(eng, oracle, pyref, M):
         eng.sign_batch(pyref.R.to_bytes(32, "big"), [b"m"], dst)
     with pytest.raises(M.InvalidScalarBytes):
         eng.sk_to_pk_batch(b"\xff" * 32, 1)
+
+
+def test_abi_edge_cases(eng, oracle, M):
+    """Argument errors and empty batches straight at the C ABI (no Python conveniences in between)."""
+    import ctypes
+    lib = M.load_library()
+    ctx = eng._ctx
+    z = ctypes.c_size_t(0)
+    buf = (ctypes.c_uint8 * 512)()
+    off = (ctypes.c_uint64 * 2)(0, 0)
+    valid = ctypes.c_int(7)
+    assert lib.blsbn254_pairing_batch(ctx, None, None, z, None) == 0                       # n = 0 is a no-op
+    assert lib.blsbn254_pairing_batch(ctx, None, buf, ctypes.c_size_t(1), buf) == -1       # NULL operand
+    assert lib.blsbn254_verify_batch(ctx, None, None, off, None, z, None, z, None) == 0
+    assert lib.blsbn254_verify_batch(ctx, buf, buf, None, buf, ctypes.c_size_t(1), buf, z, buf) == -1
+    assert lib.blsbn254_aggregate_verify(ctx, None, None, off, z, buf, None, z, ctypes.byref(valid)) == 0 and valid.value == 0
+    assert lib.blsbn254_final_exponentiation(None, buf, ctypes.c_size_t(1), buf) == -1     # NULL ctx
+    bad_off = (ctypes.c_uint64 * 2)(5, 2)                                                   # decreasing offsets
+    assert lib.blsbn254_hash_to_g1_batch(ctx, buf, bad_off, ctypes.c_size_t(1), buf, ctypes.c_size_t(3), buf) == -1
+    # messages window that does not start at offset 0
+    msgs = b"XXXXhello"
+    o2 = (ctypes.c_uint64 * 2)(4, 9)
+    out = (ctypes.c_uint8 * 64)()
+    dst = b"dst"
+    assert lib.blsbn254_hash_to_g1_batch(ctx, msgs, o2, ctypes.c_size_t(1), dst, ctypes.c_size_t(3), out) == 0
+    assert bytes(out) == oracle.hash_to_g1_batch([b"hello"], dst)
+    # a second context on the same device works independently
+    e2 = M.Engine(0)
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    assert e2.pairing_batch(G1, G2, 1) == eng.pairing_batch(G1, G2, 1)
+    e2.close()

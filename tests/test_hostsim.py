@@ -60,7 +60,7 @@ def test_pairing_path_bit_exact_and_bounded(hs, oracle, pyref, kats):
         p, q = oracle.g1_mul(G1, rnd.randrange(1, pyref.R)), oracle.g2_mul(G2, rnd.randrange(1, pyref.R))
         hs.hs_miller1(p, q, ml, ctypes.byref(st)); assert ml.raw == oracle.miller_loop_batch(p, q, 1)
         hs.hs_pairing(p, q, gt); assert gt.raw == oracle.pairing_batch(p, q, 1)
-    assert hs.hs_expx_mem_matches(oracle.miller_loop_batch(G1, G2, 1)) == 1       # LDS-parked operand variant
+    assert hs.hs_expx_chain_matches(oracle.miller_loop_batch(G1, G2, 1)) == 1       # t^x: addition chain == binary ladder
     ident = bytes(32) + (1).to_bytes(32, "big")
     hs.hs_miller1(ident, G2, ml, ctypes.byref(st))
     assert st.value == 7 and ml.raw == (1).to_bytes(32, "big") + bytes(352)
@@ -106,5 +106,8 @@ def test_hash_checks_and_verify(hs, oracle, pyref, kats):
     negG2 = pyref.g2_to_bytes(pyref.g2_neg(pyref.G2_GEN))
     H = oracle.hash_to_g1_batch([msg], dst)
     assert ml.raw == oracle.multi_miller_loop(sig + H, negG2 + pk, 2)        # fixed-Q line table == on-the-fly lines
+    ml2 = ctypes.create_string_buffer(384); fl = ctypes.c_int(0)
+    hs.hs_miller_verify_ws(pk, sig, H, ml2, ctypes.byref(fl))                # workspace-reload loop (the kernel's) == register loop
+    assert ml2.raw == ml.raw and fl.value == 3
     assert hs.hs_verify(pk, b"hellp", 5, sig, dst, len(dst), None) == 0
     assert hs.hs_verify(synth.NON_SUBGROUP_PK, msg, len(msg), sig, dst, len(dst), None) == 0
