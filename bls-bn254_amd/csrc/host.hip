@@ -304,7 +304,7 @@ int blsbn254_final_exponentiation(blsbn254_ctx* c, const uint8_t* ml, size_t n, 
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, c->in_a.reserve(384 * n)); HIPCHK(c, c->out.reserve(384 * n)); HIPCHK(c, c->f_ws.reserve(n * 108 * 4)); HIPCHK(c, c->status.reserve(n));
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, ml, 384 * n, hipMemcpyHostToDevice, c->stream));
-  LAUNCH(c, "fp12_from_bytes", k_fp12_from_bytes, n, (const uint8_t*)c->in_a.p, n, (int32_t*)c->f_ws.p, (uint8_t*)c->status.p);
+  LAUNCH(c, "fp12_from_bytes", k_fp12_from_bytes, n, (const uint8_t*)c->in_a.p, n, (int32_t*)c->f_ws.p, n, (uint8_t*)c->status.p);
   int bad; int rc = first_bad(c, (const uint8_t*)c->status.p, n, 1, 1, &bad);
   if (rc) return rc;
   if (bad >= 0) return BLSBN254_ERR_GT;
@@ -413,60 +413,104 @@ int blsbn254_verify_batch(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* ms
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
-int blsbn254_aggregate_verify(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
-                              const uint8_t agg_sig[64], const uint8_t* dst, size_t dst_len, int* valid) {
-  if (!c || !valid || !agg_sig || !off || (n && !pks) || (dst_len && !dst)) return BLSBN254_E_ARG;
-  *valid = 0;
-  if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
-  uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
-  if (rc) return rc;
-  rc = stage_msgs(c, msgs, off, n);
-  if (rc) return rc;
-  size_t m = n + 1;                                   // slot n holds the (agg_sig, -G2gen) pair
-  HIPCHK(c, c->in_a.reserve(128 * n)); HIPCHK(c, c->in_b.reserve(64 + 128));
-  HIPCHK(c, c->h_ws.reserve(n * 18 * 4)); HIPCHK(c, c->f_ws.reserve(m * 108 * 4));
-  HIPCHK(c, c->flags.reserve(n)); HIPCHK(c, c->sub_ok.reserve(n)); HIPCHK(c, c->status.reserve(8)); HIPCHK(c, c->misc.reserve(64)); HIPCHK(c, c->bitmap.reserve(16));
-  HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * n, hipMemcpyHostToDevice, c->stream));
-  // -G2gen = (x, p - y) of the generator fp2.rs:305-333
-  static const uint8_t neg_g2[128] = {
-    0x19,0x8e,0x93,0x93,0x92,0x0d,0x48,0x3a,0x72,0x60,0xbf,0xb7,0x31,0xfb,0x5d,0x25,0xf1,0xaa,0x49,0x33,0x35,0xa9,0xe7,0x12,0x97,0xe4,0x85,0xb7,0xae,0xf3,0x12,0xc2,
-    0x18,0x00,0xde,0xef,0x12,0x1f,0x1e,0x76,0x42,0x6a,0x00,0x66,0x5e,0x5c,0x44,0x79,0x67,0x43,0x22,0xd4,0xf7,0x5e,0xda,0xdd,0x46,0xde,0xbd,0x5c,0xd9,0x92,0xf6,0xed,
-    0x27,0x5d,0xc4,0xa2,0x88,0xd1,0xaf,0xb3,0xcb,0xb1,0xac,0x09,0x18,0x75,0x24,0xc7,0xdb,0x36,0x39,0x5d,0xf7,0xbe,0x3b,0x99,0xe6,0x73,0xb1,0x3a,0x07,0x5a,0x65,0xec,
-    0x1d,0x9b,0xef,0xcd,0x05,0xa5,0x32,0x3e,0x6d,0xa4,0xd4,0x35,0xf3,0xb6,0x17,0xcd,0xb3,0xaf,0x83,0x28,0x5c,0x2d,0xf7,0x11,0xef,0x39,0xc0,0x15,0x71,0x82,0x7f,0x9d};
-  uint8_t last[64 + 128];
-  std::memcpy(last, agg_sig, 64); std::memcpy(last + 64, neg_g2, 128);
-  HIPCHK(c, hipMemcpyAsync(c->in_b.p, last, sizeof last, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));         // `last` is on the stack
-  int32_t* f = (int32_t*)c->f_ws.p;
-  LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, (uint8_t*)nullptr, 0);
-  LAUNCH(c, "g2_check", k_g2_check, n, (const uint8_t*)c->in_a.p, n, (uint8_t*)c->sub_ok.p, (uint8_t*)nullptr);
-  LAUNCH(c, "miller_hpk", k_miller_hpk, n, (const int32_t*)c->h_ws.p, (const uint8_t*)c->in_a.p, n, f, m, (uint8_t*)c->flags.p);
-  LAUNCH(c, "miller_1", k_miller_1, 1, (const uint8_t*)c->in_b.p, (const uint8_t*)c->in_b.p + 64, (size_t)1, f + n, m, (uint8_t*)c->status.p);
-  LAUNCH(c, "g1_check", k_g1_check, 1, (const uint8_t*)c->in_b.p, (size_t)1, (uint8_t*)c->bitmap.p);
-  int* d_flags = (int*)c->misc.p;                     // [0] all pks ok, [1] product == 1 after final exp
-  int init[2] = {1, 0};
-  HIPCHK(c, hipMemcpyAsync(d_flags, init, 8, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  LAUNCH(c, "and_reduce", k_and_reduce, n, (const uint8_t*)c->flags.p, (const uint8_t*)c->sub_ok.p, n, d_flags);
-  // product tree over the m Miller values (stride m)
-  HIPCHK(c, c->f_ws2.reserve(((m + 1) / 2) * 108 * 4));
-  int32_t* a = f; int32_t* b = (int32_t*)c->f_ws2.p;
-  size_t sa = m, cnt = m;
+// -G2gen = (x, p - y) of the generator fp2.rs:305-333, as bytes
+static const uint8_t NEG_G2_BYTES[128] = {
+  0x19,0x8e,0x93,0x93,0x92,0x0d,0x48,0x3a,0x72,0x60,0xbf,0xb7,0x31,0xfb,0x5d,0x25,0xf1,0xaa,0x49,0x33,0x35,0xa9,0xe7,0x12,0x97,0xe4,0x85,0xb7,0xae,0xf3,0x12,0xc2,
+  0x18,0x00,0xde,0xef,0x12,0x1f,0x1e,0x76,0x42,0x6a,0x00,0x66,0x5e,0x5c,0x44,0x79,0x67,0x43,0x22,0xd4,0xf7,0x5e,0xda,0xdd,0x46,0xde,0xbd,0x5c,0xd9,0x92,0xf6,0xed,
+  0x27,0x5d,0xc4,0xa2,0x88,0xd1,0xaf,0xb3,0xcb,0xb1,0xac,0x09,0x18,0x75,0x24,0xc7,0xdb,0x36,0x39,0x5d,0xf7,0xbe,0x3b,0x99,0xe6,0x73,0xb1,0x3a,0x07,0x5a,0x65,0xec,
+  0x1d,0x9b,0xef,0xcd,0x05,0xa5,0x32,0x3e,0x6d,0xa4,0xd4,0x35,0xf3,0xb6,0x17,0xcd,0xb3,0xaf,0x83,0x28,0x5c,0x2d,0xf7,0x11,0xef,0x39,0xc0,0x15,0x71,0x82,0x7f,0x9d};
+
+// in-place product tree over `cnt` Fp12 values at a (stride sa); result pointer / stride returned
+static int fp12_tree(blsbn254_ctx* c, int32_t* a, size_t cnt, size_t sa, int32_t** res, size_t* rs) {
+  HIPCHK(c, c->f_ws2.reserve(((cnt + 1) / 2) * 108 * 4 + 432));
+  int32_t* b = (int32_t*)c->f_ws2.p;
   while (cnt > 1) {
     size_t mo = (cnt + 1) / 2;
     LAUNCH(c, "fp12_mul_pairs", k_fp12_mul_pairs, mo, (const int32_t*)a, cnt, sa, b, mo);
     std::swap(a, b); sa = mo; cnt = mo;
   }
-  rc = run_final_exp(c, a, 1, sa, 3, nullptr, nullptr, nullptr, nullptr, d_flags + 1);
+  *res = a; *rs = sa;
+  return 0;
+}
+int blsbn254_aggregate_partial(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
+                               const uint8_t* dst, size_t dst_len, uint8_t ml_out[384], int* all_pks_ok) {
+  if (!c || !ml_out || !all_pks_ok || !off || (n && !pks) || (dst_len && !dst)) return BLSBN254_E_ARG;
+  *all_pks_ok = 1;
+  if (n == 0) { std::memset(ml_out, 0, 384); ml_out[31] = 1; return 0; }
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
   if (rc) return rc;
-  int h_flags[2]; uint8_t sig_st, sig_on_curve;
-  HIPCHK(c, hipMemcpyAsync(h_flags, d_flags, 8, hipMemcpyDeviceToHost, c->stream));
+  rc = stage_msgs(c, msgs, off, n);
+  if (rc) return rc;
+  HIPCHK(c, c->in_a.reserve(128 * n)); HIPCHK(c, c->h_ws.reserve(n * 18 * 4)); HIPCHK(c, c->f_ws.reserve(n * 108 * 4));
+  HIPCHK(c, c->flags.reserve(n)); HIPCHK(c, c->sub_ok.reserve(n)); HIPCHK(c, c->misc.reserve(64)); HIPCHK(c, c->out.reserve(384));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * n, hipMemcpyHostToDevice, c->stream));
+  int32_t* f = (int32_t*)c->f_ws.p;
+  LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, (uint8_t*)nullptr, 0);
+  LAUNCH(c, "g2_check", k_g2_check, n, (const uint8_t*)c->in_a.p, n, (uint8_t*)c->sub_ok.p, (uint8_t*)nullptr);
+  LAUNCH(c, "miller_hpk", k_miller_hpk, n, (const int32_t*)c->h_ws.p, (const uint8_t*)c->in_a.p, n, f, n, (uint8_t*)c->flags.p);
+  int* d_ok = (int*)c->misc.p;
+  int one = 1;
+  HIPCHK(c, hipMemcpyAsync(d_ok, &one, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  LAUNCH(c, "and_reduce", k_and_reduce, n, (const uint8_t*)c->flags.p, (const uint8_t*)c->sub_ok.p, n, d_ok);
+  int32_t* res; size_t rs;
+  rc = fp12_tree(c, f, n, n, &res, &rs);
+  if (rc) return rc;
+  LAUNCH(c, "fp12_to_bytes", k_fp12_to_bytes, 1, (const int32_t*)res, (size_t)1, rs, (uint8_t*)c->out.p);
+  HIPCHK(c, hipMemcpyAsync(ml_out, c->out.p, 384, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(all_pks_ok, d_ok, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int blsbn254_aggregate_finish(blsbn254_ctx* c, const uint8_t* partials, size_t k, const uint8_t agg_sig[64], int* valid) {
+  if (!c || !valid || !agg_sig || (k && !partials)) return BLSBN254_E_ARG;
+  *valid = 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t m = k + 1;                                   // slot k holds ML(agg_sig, -G2gen)
+  HIPCHK(c, c->in_a.reserve(384 * (k ? k : 1))); HIPCHK(c, c->in_b.reserve(64 + 128)); HIPCHK(c, c->f_ws.reserve(m * 108 * 4));
+  HIPCHK(c, c->status.reserve(k + 8)); HIPCHK(c, c->misc.reserve(64)); HIPCHK(c, c->bitmap.reserve(16));
+  int32_t* f = (int32_t*)c->f_ws.p;
+  uint8_t last[64 + 128];
+  std::memcpy(last, agg_sig, 64); std::memcpy(last + 64, NEG_G2_BYTES, 128);
+  HIPCHK(c, hipMemcpyAsync(c->in_b.p, last, sizeof last, hipMemcpyHostToDevice, c->stream));
+  if (k) HIPCHK(c, hipMemcpyAsync(c->in_a.p, partials, 384 * k, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));         // `last` is on the stack
+  if (k) {
+    // partials arrive as bytes: decode into slots 0..k-1 of the stride-m array
+    LAUNCH(c, "fp12_from_bytes", k_fp12_from_bytes, k, (const uint8_t*)c->in_a.p, k, f, m, (uint8_t*)c->status.p);
+    int bad; int rc = first_bad(c, (const uint8_t*)c->status.p, k, 1, 1, &bad);
+    if (rc) return rc;
+    if (bad >= 0) return BLSBN254_ERR_GT;
+  }
+  LAUNCH(c, "miller_1", k_miller_1, 1, (const uint8_t*)c->in_b.p, (const uint8_t*)c->in_b.p + 64, (size_t)1, f + k, m, (uint8_t*)c->status.p);
+  LAUNCH(c, "g1_check", k_g1_check, 1, (const uint8_t*)c->in_b.p, (size_t)1, (uint8_t*)c->bitmap.p);
+  int32_t* res; size_t rs;
+  int rc = fp12_tree(c, f, m, m, &res, &rs);
+  if (rc) return rc;
+  int* d_one = (int*)c->misc.p;
+  rc = run_final_exp(c, res, 1, rs, 3, nullptr, nullptr, nullptr, nullptr, d_one);
+  if (rc) return rc;
+  int h_one = 0; uint8_t sig_st, sig_on_curve;
+  HIPCHK(c, hipMemcpyAsync(&h_one, d_one, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(&sig_st, c->status.p, 1, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipMemcpyAsync(&sig_on_curve, c->bitmap.p, 1, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   bool sig_ok = (sig_st & 7) == 3 && (sig_on_curve & 1);      // decodes, not the identity, on the curve
-  *valid = (sig_ok && h_flags[0] == 1 && h_flags[1] == 1) ? 1 : 0;
+  *valid = (sig_ok && h_one == 1) ? 1 : 0;
+  return 0;
+}
+int blsbn254_aggregate_verify(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
+                              const uint8_t agg_sig[64], const uint8_t* dst, size_t dst_len, int* valid) {
+  if (!c || !valid || !agg_sig || !off || (n && !pks) || (dst_len && !dst)) return BLSBN254_E_ARG;
+  *valid = 0;
+  if (n == 0) return 0;
+  uint8_t ml[384]; int ok = 0, v = 0;
+  int rc = blsbn254_aggregate_partial(c, pks, msgs, off, n, dst, dst_len, ml, &ok);
+  if (rc) return rc;
+  rc = blsbn254_aggregate_finish(c, ml, 1, agg_sig, &v);
+  if (rc) return rc;
+  *valid = (ok == 1 && v == 1) ? 1 : 0;
   return 0;
 }
 // n G1 points (limb-major projective, stride n) in c->h_ws -> their sum as 64 bytes

@@ -30,12 +30,12 @@ BN_KERNEL k_g1_check(const uint8_t* g1, size_t n, uint8_t* bitmap) {
   bool ok = i < n ? lane_g1_check(g1 + 64 * i) : false;
   write_ballot(bitmap, n, i, ok);
 }
-BN_KERNEL k_fp12_from_bytes(const uint8_t* in, size_t n, int32_t* f_ws, uint8_t* status) {
+BN_KERNEL k_fp12_from_bytes(const uint8_t* in, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   bool ok;
   Fp12 f = fp12_from_be(in + 384 * i, ok);
-  fp12_store_limbs(f_ws + i, n, f);
+  fp12_store_limbs(f_ws + i, f_stride, f);
   status[i] = ok ? 1 : 0;
 }
 BN_KERNEL k_fp12_to_bytes(const int32_t* f_ws, size_t n, size_t stride, uint8_t* out) {

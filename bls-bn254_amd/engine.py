@@ -200,6 +200,22 @@ class Engine:
                                                       ctypes.c_size_t(len(dst)), ctypes.byref(valid)))
         return bool(valid.value)
 
+    def aggregate_partial(self, pks, msgs, dst=DEFAULT_DST):
+        """(384-byte Fp12 partial product of ML(H(msg_i), pk_i), all public keys valid?) for one shard."""
+        n = len(msgs)
+        data, off = pack_messages(msgs)
+        a, pa = _inbuf(pks, 128 * n); m, pm = _inbuf(data); d, pd = _inbuf(dst); o, po = _outbuf(384)
+        ok = ctypes.c_int(0)
+        self._chk(self._lib.blsbn254_aggregate_partial(self._ctx, pa, pm, off.ctypes.data_as(_u64p), ctypes.c_size_t(n), pd,
+                                                       ctypes.c_size_t(len(dst)), po, ctypes.byref(ok)))
+        return o.tobytes(), bool(ok.value)
+
+    def aggregate_finish(self, partials, k, agg_sig):
+        a, pa = _inbuf(partials, 384 * k); s, ps = _inbuf(agg_sig, 64)
+        valid = ctypes.c_int(0)
+        self._chk(self._lib.blsbn254_aggregate_finish(self._ctx, pa, ctypes.c_size_t(k), ps, ctypes.byref(valid)))
+        return bool(valid.value)
+
     def aggregate_sigs(self, sigs, n):
         a, pa = _inbuf(sigs, 64 * n); o, po = _outbuf(64)
         self._chk(self._lib.blsbn254_aggregate_sigs(self._ctx, pa, ctypes.c_size_t(n), po))

@@ -52,3 +52,23 @@ def verify_batch_sharded(verify_local, n, rank, world, dist, torch, device, grou
     local = verify_local(lo, hi) if hi > lo else torch.zeros(0, dtype=torch.uint8, device=device)
     words = allreduce_bitmap(local, lo, hi - lo, n, dist, torch, group)
     return words
+
+
+def aggregate_verify_sharded(partial_local, finish, n, rank, world, dist, torch, device, group=None):
+    """Aggregate verify over ranks: rank g computes the Fp12 partial product of its contiguous
+    share, the 384-byte partials are all-gathered (Fp12 multiplication is not an RCCL reduce op), every rank
+    finishes with the single final exponentiation.
+      partial_local(lo, hi) -> (384 bytes, all_pks_ok: bool)     finish(partials_bytes, k) -> bool"""
+    lo, hi = shard_range(n, rank, world)
+    ml, ok = partial_local(lo, hi)
+    mine = torch.frombuffer(bytearray(ml), dtype=torch.uint8).to(device)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        allp = torch.cat(parts)
+    else:
+        allp = mine
+    k = allp.numel() // 384
+    return bool(flag.item()) and n > 0 and finish(bytes(allp.cpu().numpy()), k)

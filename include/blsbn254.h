@@ -92,6 +92,13 @@ int blsbn254_verify_batch(blsbn254_ctx* ctx, const uint8_t* pks, const uint8_t* 
 /* valid = prod_i e(H(msg_i), pk_i) * e(agg_sig, -G2gen) == 1, every pk_i valid, n >= 1 */
 int blsbn254_aggregate_verify(blsbn254_ctx* ctx, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
                               const uint8_t agg_sig[64], const uint8_t* dst, size_t dst_len, int* valid);
+/* The same check split for sharding over GPUs: every rank reduces ITS (pk_i, msg_i) to one
+ * Fp12 partial product prod_i ML(H(msg_i), pk_i) (384 B; n = 0 gives Fp12::ONE) and reports whether all its
+ * public keys validated; the partials are exchanged (all-gather of 384-byte records, Fp12 multiplication is
+ * not an RCCL reduce op) and any rank finishes: valid = FE(prod partials * ML(agg_sig, -G2gen)) == 1. */
+int blsbn254_aggregate_partial(blsbn254_ctx* ctx, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
+                               const uint8_t* dst, size_t dst_len, uint8_t ml_out[384], int* all_pks_ok);
+int blsbn254_aggregate_finish(blsbn254_ctx* ctx, const uint8_t* partials /* k*384 */, size_t k, const uint8_t agg_sig[64], int* valid);
 /* impl Sum for G1Projective, g1.rs:561-565 */
 int blsbn254_aggregate_sigs(blsbn254_ctx* ctx, const uint8_t* sigs, size_t n, uint8_t out[64]);
 /* sum_i lambda_i * sig_i with Lagrange coefficients at 0 for the t distinct non-zero ids

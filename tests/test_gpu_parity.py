@@ -317,3 +317,22 @@ def test_abi_edge_cases(eng, oracle, M):
     G1, G2 = oracle.g1_generator(), oracle.g2_generator()
     assert e2.pairing_batch(G1, G2, 1) == eng.pairing_batch(G1, G2, 1)
     e2.close()
+
+
+def test_aggregate_partial_finish(eng, oracle, M):
+    """The sharded form of aggregate verify: two partial products + finish == the one-call result."""
+    dst = M.DEFAULT_DST
+    n = 21
+    sks = [synth.sk_of(k) for k in range(n)]
+    pks = b"".join(oracle.sk_to_pk(s) for s in sks)
+    msgs = [synth.msg_of(i) for i in range(n)]
+    agg = oracle.aggregate_sigs(b"".join(oracle.sign(s, m, dst) for s, m in zip(sks, msgs)), n)
+    p0, ok0 = eng.aggregate_partial(pks[:128 * 8], msgs[:8], dst)
+    p1, ok1 = eng.aggregate_partial(pks[128 * 8:], msgs[8:], dst)
+    pe, oke = eng.aggregate_partial(b"", [], dst)
+    assert ok0 and ok1 and oke and pe == ONE_GT
+    h = oracle.hash_to_g1_batch(msgs[:8], dst)
+    assert p0 == oracle.multi_miller_loop(h, pks[:128 * 8], 8)                  # partial == oracle Miller product
+    assert eng.aggregate_finish(p0 + p1 + pe, 3, agg) is True
+    assert eng.aggregate_finish(p0, 1, agg) is False
+    assert eng.aggregate_partial(synth.NON_SUBGROUP_PK, [b"m"], dst)[1] is False

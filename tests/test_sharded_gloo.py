@@ -38,6 +38,55 @@ def _worker(rank, world, port, n, outdir):
     dist.destroy_process_group()
 
 
+def _agg_worker(rank, world, port, n, outdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import blsbn254_loader
+    blsbn254_loader.load()
+    sharded = __import__("bls_bn254_amd.sharded", fromlist=["x"])
+    from oracle import oracle as O
+    from oracle.pyref import bn254 as B
+    from tests import synth
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    dst = b"TEST_DST"
+    sks = [synth.sk_of(k) for k in range(n)]
+    pks = [O.sk_to_pk(s) for s in sks]
+    msgs = [synth.msg_of(i) for i in range(n)]
+    agg = O.aggregate_sigs(b"".join(O.sign(s, m, dst) for s, m in zip(sks, msgs)), n)
+    neg_g2 = B.g2_to_bytes(B.g2_neg(B.G2_GEN))
+    one = (1).to_bytes(32, "big") + bytes(352)
+
+    def partial_local(lo, hi):                      # oracle stand-in for Engine.aggregate_partial
+        if hi == lo:
+            return one, True
+        h = O.hash_to_g1_batch(msgs[lo:hi], dst)
+        ok = O.g2_check_batch(b"".join(pks[lo:hi]), hi - lo) == synth.bitmap_of([True] * (hi - lo))
+        return O.multi_miller_loop(h, b"".join(pks[lo:hi]), hi - lo), ok
+
+    def finish(partials, k):                        # oracle stand-in for Engine.aggregate_finish
+        acc = O.miller_loop_batch(agg, neg_g2, 1)
+        for i in range(k):
+            acc = O.gt_mul(acc, partials[384 * i:384 * i + 384])
+        return O.final_exponentiation(acc, 1) == one
+    res = []
+    res.append(sharded.aggregate_verify_sharded(partial_local, finish, n, rank, world, dist, torch, torch.device("cpu")))
+    msgs[1] = b"tampered"
+    res.append(sharded.aggregate_verify_sharded(partial_local, finish, n, rank, world, dist, torch, torch.device("cpu")))
+    np.save(os.path.join(outdir, "a%d.npy" % rank), np.array(res, dtype=np.uint8))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_aggregate_allgather(tmp_path):
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    O.build()
+    mp.spawn(_agg_worker, args=(2, _free_port(), 5, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert np.load(tmp_path / ("a%d.npy" % r)).tolist() == [1, 0]
+
+
 @pytest.mark.parametrize("n", [37, 64])
 def test_world2_bitmap_allreduce(tmp_path, n):
     import torch.multiprocessing as mp
