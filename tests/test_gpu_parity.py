@@ -336,3 +336,37 @@ def test_aggregate_partial_finish(eng, oracle, M):
     assert eng.aggregate_finish(p0 + p1 + pe, 3, agg) is True
     assert eng.aggregate_finish(p0, 1, agg) is False
     assert eng.aggregate_partial(synth.NON_SUBGROUP_PK, [b"m"], dst)[1] is False
+
+
+def test_randomized_differential(eng, oracle, pyref, M):
+    """Larger seeded differential run: 1500 random pairings (random multiples of the generators, identities and
+    negations mixed in), 1500 random-length messages hashed to G1, 600 point encodings of which a third are
+    malformed, all compared byte for byte with the oracle."""
+    rnd = random.Random(20261004)
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    n = 1500
+    base1 = [oracle.g1_mul(G1, rnd.randrange(1, pyref.R)) for _ in range(40)] + [IDENT1]
+    base2 = [oracle.g2_mul(G2, rnd.randrange(1, pyref.R)) for _ in range(40)] + [IDENT2]
+    # more distinct points cheaply: sums of pairs
+    pts1 = [oracle.g1_add(rnd.choice(base1), rnd.choice(base1)) for _ in range(200)] + base1
+    pts2 = [oracle.g2_add(rnd.choice(base2), rnd.choice(base2)) for _ in range(200)] + base2
+    g1 = b"".join(rnd.choice(pts1) for _ in range(n))
+    g2 = b"".join(rnd.choice(pts2) for _ in range(n))
+    assert eng.pairing_batch(g1, g2, n) == oracle.pairing_batch(g1, g2, n)
+    assert eng.multi_miller_loop(g1[:64 * 300], g2[:128 * 300], 300) == oracle.multi_miller_loop(g1[:64 * 300], g2[:128 * 300], 300)
+    msgs = [bytes(rnd.getrandbits(8) for _ in range(rnd.choice([0, 1, 31, 32, 33, 55, 56, 64, 100, 200]))) for _ in range(n)]
+    dst = bytes(rnd.getrandbits(8) for _ in range(43))
+    assert eng.hash_to_g1_batch(msgs, dst) == oracle.hash_to_g1_batch(msgs, dst)
+    # encodings: valid points, off-curve points, non-canonical coordinates
+    enc1, enc2 = [], []
+    for i in range(600):
+        a, b = bytearray(rnd.choice(pts1)), bytearray(rnd.choice(pts2))
+        k = i % 3
+        if k == 1:
+            a[rnd.randrange(64)] ^= 1 << rnd.randrange(8); b[rnd.randrange(128)] ^= 1 << rnd.randrange(8)
+        elif k == 2:
+            a[0] |= 0x80; b[64] |= 0xc0
+        enc1.append(bytes(a)); enc2.append(bytes(b))
+    e1, e2 = b"".join(enc1), b"".join(enc2)
+    assert eng.g1_check_batch(e1, 600) == oracle.g1_check_batch(e1, 600)
+    assert eng.g2_check_batch(e2, 600) == oracle.g2_check_batch(e2, 600)
