@@ -230,6 +230,37 @@ BN_FUNC G2P g2_clear_cofactor(const G2P& p) {               // g2.rs:685-693
   return proj_add(proj_add(p0, p1), proj_add(p2, p3));
 }
 
+// ------------------------------------------------------------------ compressed codecs
+// G1: 32 B = x big-endian, bit 255 = parity of y (G1Affine::to_compressed, g1.rs:283-288).  Decoding picks the
+// root whose parity equals the flag: the corrected rule (the reference's from_compressed selects on
+// y.is_high() ^ flag, g1.rs:320, E8).  G2: 64 B = x.c1 || x.c0, bit 255 of the first byte = sgn0(y)
+// (g2.rs:274-283, :309-340).  x == 0 <-> identity.
+BN_FUNC void g1_compress(uint8_t* out, const G1A& a) {
+  Fp x = fp_select(a.inf, fp_zero(), a.x), y = fp_select(a.inf, fp_one(), a.y);
+  fp_to_be(out, x);
+  out[0] |= (uint8_t)(fp_sgn0(y) << 7);
+}
+BN_FUNC G1A g1_decompress(const uint8_t* in, bool& ok) {
+  uint8_t xb[32];
+  for (int i = 0; i < 32; ++i) xb[i] = in[i];
+  int flag = xb[0] >> 7; xb[0] &= 0x7f;
+  bool okx, sq;
+  G1A r;
+  r.x = fp_from_be(xb, okx);
+  r.inf = okx & fp_is_zero(r.x);
+  Fp rhs = fp_norm(fp_add(fp_mul(fp_sqr(r.x), r.x), fp_const(bnc::THREE)));
+  Fp y = fp_sqrt_cand(rhs, sq);
+  bool flip = fp_sgn0(y) != flag;
+  r.y = fp_select(flip, fp_norm(fp_neg(y)), y);
+  ok = okx & (r.inf | sq);
+  return r;
+}
+BN_FUNC void g2_compress(uint8_t* out, const G2A& a) {
+  Fp2 x = fp2_select(a.inf, fp2_zero(), a.x), y = fp2_select(a.inf, fp2_one(), a.y);
+  fp_to_be(out, x.c1); fp_to_be(out + 32, x.c0);
+  out[0] |= (uint8_t)(fp2_sgn0(y) << 7);
+}
+
 // ------------------------------------------------------------------ SVDW maps
 // Straight-line Shallue-van de Woestijne (RFC 9380 F.1), Z = 1, following fp.rs:292-370.  The two
 // is_square tests and the final sqrt of the reference (three Euler/sqrt exponentiations) are each
@@ -297,6 +328,22 @@ BN_FUNC Fp2 fp2_sqrt(const Fp2& a_in) {
   Fp2 b = fp2_pow(fp2_norm(fp2_add(alpha, fp2_one())), BN_EXP(EXP_PM1_2));
   Fp2 r = fp2_mul(b, x0);
   return fp2_select(neg_one, alt, r);
+}
+BN_FUNC G2A g2_decompress(const uint8_t* in, bool& ok) {
+  uint8_t xb[32];
+  for (int i = 0; i < 32; ++i) xb[i] = in[i];
+  int flag = xb[0] >> 7; xb[0] &= 0x7f;
+  bool o0, o1;
+  G2A r;
+  r.x.c1 = fp_from_be(xb, o0); r.x.c0 = fp_from_be(in + 32, o1);
+  r.inf = o0 & o1 & fp2_is_zero(r.x);
+  Fp2 rhs = fp2_norm(fp2_add(fp2_mul(fp2_sqr(r.x), r.x), fp2_const(bnc::B2)));
+  Fp2 y = fp2_sqrt(rhs);
+  bool sq = fp2_is_zero(fp2_sub(fp2_sqr(y), rhs));
+  bool flip = fp2_sgn0(y) != flag;
+  r.y = fp2_select(flip, fp2_norm(fp2_neg(y)), y);
+  ok = o0 & o1 & (r.inf | sq);
+  return r;
 }
 BN_FUNC G2A svdw_g2(const Fp2& u_in) {                      // fp2.rs:224-286
   Fp2 u = fp2_norm(u_in);

@@ -559,6 +559,29 @@ int blsbn254_threshold_combine(blsbn254_ctx* c, const uint8_t* ids, const uint8_
   return g1_sum_to_bytes(c, t, out_sig);
 }
 
+// ---------------- compressed codecs
+static int codec_common(blsbn254_ctx* c, const uint8_t* in, size_t n, uint8_t* out, int g2, int mode) {
+  if (!c || (n && (!in || !out))) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t full = g2 ? 128 : 64, comp = full / 2;
+  size_t isz = mode == 0 ? full : comp, osz = mode == 0 ? comp : full;
+  HIPCHK(c, c->in_a.reserve(isz * n)); HIPCHK(c, c->out.reserve(osz * n)); HIPCHK(c, c->status.reserve(n));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, in, isz * n, hipMemcpyHostToDevice, c->stream));
+  if (g2) { LAUNCH(c, "g2_codec", k_g2_codec, n, (const uint8_t*)c->in_a.p, n, (uint8_t*)c->out.p, (uint8_t*)c->status.p, mode); }
+  else { LAUNCH(c, "g1_codec", k_g1_codec, n, (const uint8_t*)c->in_a.p, n, (uint8_t*)c->out.p, (uint8_t*)c->status.p, mode); }
+  int bad; int rc = first_bad(c, (const uint8_t*)c->status.p, n, 1, 1, &bad);
+  if (rc) return rc;
+  if (bad >= 0) return g2 ? BLSBN254_ERR_G2 : BLSBN254_ERR_G1;
+  HIPCHK(c, hipMemcpyAsync(out, c->out.p, osz * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int blsbn254_g1_compress_batch(blsbn254_ctx* c, const uint8_t* g1, size_t n, uint8_t* out) { return codec_common(c, g1, n, out, 0, 0); }
+int blsbn254_g1_decompress_batch(blsbn254_ctx* c, const uint8_t* in, size_t n, uint8_t* g1) { return codec_common(c, in, n, g1, 0, 1); }
+int blsbn254_g2_compress_batch(blsbn254_ctx* c, const uint8_t* g2, size_t n, uint8_t* out) { return codec_common(c, g2, n, out, 1, 0); }
+int blsbn254_g2_decompress_batch(blsbn254_ctx* c, const uint8_t* in, size_t n, uint8_t* g2) { return codec_common(c, in, n, g2, 1, 1); }
+
 // ---------------- signing side
 int blsbn254_sign_batch(blsbn254_ctx* c, const uint8_t* sks, const uint8_t* msgs, const uint64_t* off, size_t n,
                         const uint8_t* dst, size_t dst_len, uint8_t* sigs_out) {

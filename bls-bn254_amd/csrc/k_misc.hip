@@ -89,6 +89,23 @@ BN_KERNEL k_lagrange(const uint8_t* ids, size_t t, uint8_t* scalars, uint8_t* st
   fr_to_be(scalars + 32 * i, lam);
   status[i] = ok ? 1 : 0;
 }
+// compressed codecs: mode 0 compress (uncompressed in -> compressed out), 1 decompress; status 1 = ok
+BN_KERNEL k_g1_codec(const uint8_t* in, size_t n, uint8_t* out, uint8_t* status, int mode) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool ok;
+  if (mode == 0) { G1A p = g1_decode(in + 64 * i, ok); g1_compress(out + 32 * i, p); }
+  else { G1A p = g1_decompress(in + 32 * i, ok); g1_encode(out + 64 * i, p); }
+  status[i] = ok ? 1 : 0;
+}
+BN_KERNEL k_g2_codec(const uint8_t* in, size_t n, uint8_t* out, uint8_t* status, int mode) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool ok;
+  if (mode == 0) { G2A q = g2_decode(in + 128 * i, ok); g2_compress(out + 64 * i, q); }
+  else { G2A q = g2_decompress(in + 64 * i, ok); g2_encode(out + 128 * i, q); }
+  status[i] = ok ? 1 : 0;
+}
 // VALU roofline probe: 8 independent 64-bit multiply-accumulate chains per lane (compiler-selected
 // v_mad_u64_u32, no shared VCC), every CU busy at 4 waves per SIMD.  The denominator of bench.py's
 // roofline.frac is measured in the same run (BASELINE.md section 3 "same-run rule").

@@ -33,6 +33,8 @@ BN_KERNEL k_g1_to_bytes(const int32_t* ws, size_t stride, uint8_t* out);
 BN_KERNEL k_sign(const uint8_t* sks, const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
                  uint8_t* sigs, uint8_t* status);
 BN_KERNEL k_sk_to_pk(const uint8_t* sks, size_t n, uint8_t* pks, uint8_t* status);
+BN_KERNEL k_g1_codec(const uint8_t* in, size_t n, uint8_t* out, uint8_t* status, int mode);
+BN_KERNEL k_g2_codec(const uint8_t* in, size_t n, uint8_t* out, uint8_t* status, int mode);
 BN_KERNEL k_lagrange(const uint8_t* ids, size_t t, uint8_t* scalars, uint8_t* status);
 __global__ void __launch_bounds__(256) k_valu_peak(uint32_t* out, uint32_t seed, int iters);
 __global__ void k_status_reduce(const uint8_t* status, size_t n, uint8_t want_mask, uint8_t want_val, int* first_bad);

@@ -226,6 +226,17 @@ class Engine:
         self._chk(self._lib.blsbn254_threshold_combine(self._ctx, pa, ps, ctypes.c_size_t(t), po))
         return o.tobytes()
 
+    # ---- compressed codecs
+    def _codec(self, fn, data, n, isz, osz):
+        a, pa = _inbuf(data, isz * n); o, po = _outbuf(osz * n)
+        self._chk(fn(self._ctx, pa, ctypes.c_size_t(n), po))
+        return o[:osz * n].tobytes()
+
+    def g1_compress_batch(self, g1, n): return self._codec(self._lib.blsbn254_g1_compress_batch, g1, n, 64, 32)
+    def g1_decompress_batch(self, c, n): return self._codec(self._lib.blsbn254_g1_decompress_batch, c, n, 32, 64)
+    def g2_compress_batch(self, g2, n): return self._codec(self._lib.blsbn254_g2_compress_batch, g2, n, 128, 64)
+    def g2_decompress_batch(self, c, n): return self._codec(self._lib.blsbn254_g2_decompress_batch, c, n, 64, 128)
+
     # ---- signing side (also used to generate large synthetic batches)
     def sign_batch(self, sks, msgs, dst=DEFAULT_DST):
         n = len(msgs)

@@ -114,6 +114,18 @@ int blsbn254_sign_batch(blsbn254_ctx* ctx, const uint8_t* sks, const uint8_t* ms
 /* pk_i = [sk_i] G2gen: Mul<Scalar> for G2Projective (g2.rs:866-886) */
 int blsbn254_sk_to_pk_batch(blsbn254_ctx* ctx, const uint8_t* sks, size_t n, uint8_t* pks_out);
 
+/* ---- compressed wire codecs ------------------------------------------------- */
+/* G1 32 B: x with bit 255 = parity of y (G1Affine::to_compressed g1.rs:283-288); decompression picks the root
+ * whose parity equals the flag -- the corrected rule: the reference's from_compressed (g1.rs:311-328) selects
+ * on y.is_high() ^ flag and mis-decodes about half of G1.  G2 64 B: x.c1 || x.c0 with
+ * bit 255 = sgn0(y) (g2.rs:274-283, :309-340).  An operand that does not decode (coordinate >= p, or no
+ * point with that x) returns BLSBN254_ERR_G1 / _G2.  Decompressed points are on the curve by construction;
+ * G2 subgroup membership still has to be checked (blsbn254_g2_check_batch). */
+int blsbn254_g1_compress_batch(blsbn254_ctx* ctx, const uint8_t* g1 /* n*64 */, size_t n, uint8_t* out /* n*32 */);
+int blsbn254_g1_decompress_batch(blsbn254_ctx* ctx, const uint8_t* in /* n*32 */, size_t n, uint8_t* g1 /* n*64 */);
+int blsbn254_g2_compress_batch(blsbn254_ctx* ctx, const uint8_t* g2 /* n*128 */, size_t n, uint8_t* out /* n*64 */);
+int blsbn254_g2_decompress_batch(blsbn254_ctx* ctx, const uint8_t* in /* n*64 */, size_t n, uint8_t* g2 /* n*128 */);
+
 /* ---- device-resident variants (plumbing for callers that already hold the batch in HBM) ----- */
 /* All d_* pointers are device pointers on ctx's GPU.  Work is enqueued on ctx's stream and is
  * complete after blsbn254_ctx_synchronize().  d_valid_bitmap needs ceil(n/8) bytes. */

@@ -1092,6 +1092,57 @@ void oracle_verify_core_counts(uint64_t out[4]) {
   out[3] = (u64)lines;
   (void)g;
 }
+/* Compressed codecs.  G1: 32 B = x big-endian with bit 255 = parity of y (G1Affine::to_compressed, g1.rs:283-288).
+   Decoding picks the root whose PARITY equals the flag -- the corrected rule; the reference's from_compressed
+   selects on y.is_high() ^ flag (g1.rs:320) and only round-trips points such as the generator.
+   G2: 64 B = x.c1 || x.c0 with bit 255 of the first byte = sgn0(y) (g2.rs:274-283, :309-340; self-consistent).
+   x == 0 decodes to the identity; identity compresses as x = 0 with the flag of y = 1. */
+int oracle_g1_compress(const uint8_t in[64], uint8_t out[32]) {
+  init();
+  g1a p;
+  if (!g1_decode(&p, in)) return 2;
+  if (p.inf) { p.x = FP_ZERO; p.y = FP_ONE; }
+  fp_to_be(out, p.x);
+  out[0] |= (uint8_t)(fp_sgn0(p.y) << 7);
+  return 0;
+}
+int oracle_g1_decompress(const uint8_t in[32], uint8_t out[64]) {
+  init();
+  uint8_t xb[32]; memcpy(xb, in, 32);
+  int flag = xb[0] >> 7; xb[0] &= 0x7f;
+  g1a p;
+  if (!fp_from_be(&p.x, xb)) return 2;
+  if (fp_is_zero(p.x)) { p.inf = 1; p.y = FP_ONE; g1_encode(out, p); return 0; }
+  fp y;
+  if (!fp_sqrt(&y, fp_add(fp_mul(fp_sqr(p.x), p.x), FP_B))) return 2;
+  if (fp_sgn0(y) != flag) y = fp_neg(y);
+  p.y = y; p.inf = 0;
+  g1_encode(out, p);
+  return 0;
+}
+int oracle_g2_compress(const uint8_t in[128], uint8_t out[64]) {
+  init();
+  g2a q;
+  if (!g2_decode(&q, in)) return 3;
+  if (q.inf) { q.x = F2_ZERO; q.y = F2_ONE; }
+  fp_to_be(out, q.x.c1); fp_to_be(out + 32, q.x.c0);
+  out[0] |= (uint8_t)(f2_sgn0(q.y) << 7);
+  return 0;
+}
+int oracle_g2_decompress(const uint8_t in[64], uint8_t out[128]) {
+  init();
+  uint8_t xb[32]; memcpy(xb, in, 32);
+  int flag = xb[0] >> 7; xb[0] &= 0x7f;
+  g2a q;
+  if (!fp_from_be(&q.x.c1, xb) || !fp_from_be(&q.x.c0, in + 32)) return 3;
+  if (f2_is_zero(q.x)) { q.inf = 1; q.y = F2_ONE; g2_encode(out, q); return 0; }
+  fp2 y;
+  if (!f2_sqrt(&y, f2_add(f2_mul(f2_sqr(q.x), q.x), F2_B))) return 3;
+  if (f2_sgn0(y) != flag) y = f2_neg(y);
+  q.y = y; q.inf = 0;
+  g2_encode(out, q);
+  return 0;
+}
 int oracle_gt_mul(const uint8_t a[384], const uint8_t b[384], uint8_t out[384]) {
   init();
   fp12 x, y;

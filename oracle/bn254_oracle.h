@@ -65,6 +65,10 @@ int oracle_sign(const uint8_t sk_be[32], const uint8_t* msg, size_t msg_len,
 int oracle_gt_pow(const uint8_t gt[384], const uint8_t scalar_be[32], uint8_t out[384]);
 int oracle_gt_mul(const uint8_t a[384], const uint8_t b[384], uint8_t out[384]);
 int oracle_fr_lagrange_at_zero(const uint8_t* ids, size_t t, uint8_t* out /* t*32 BE */);
+int oracle_g1_compress(const uint8_t in[64], uint8_t out[32]);
+int oracle_g1_decompress(const uint8_t in[32], uint8_t out[64]);
+int oracle_g2_compress(const uint8_t in[128], uint8_t out[64]);
+int oracle_g2_decompress(const uint8_t in[64], uint8_t out[128]);
 void oracle_sha256(const uint8_t* msg, size_t len, uint8_t out[32]);
 
 /* instrumentation: exact Fp multiplication / squaring counts of the calling thread */

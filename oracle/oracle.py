@@ -234,3 +234,15 @@ def verify_core_counts():
     a = (ctypes.c_uint64 * 4)()
     lib().oracle_verify_core_counts(a)
     return tuple(int(v) for v in a)
+
+
+def _codec(fn, data, n_in, n_out):
+    a, pa = _buf(data); o, po = _out(n_out)
+    rc = fn(pa, po)
+    return (o[:n_out].tobytes() if rc == 0 else None)
+
+
+def g1_compress(pt): return _codec(lib().oracle_g1_compress, pt, 64, 32)
+def g1_decompress(c): return _codec(lib().oracle_g1_decompress, c, 32, 64)
+def g2_compress(pt): return _codec(lib().oracle_g2_compress, pt, 128, 64)
+def g2_decompress(c): return _codec(lib().oracle_g2_decompress, c, 64, 128)

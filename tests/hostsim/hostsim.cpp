@@ -110,6 +110,20 @@ void hs_miller_verify_ws(const uint8_t* pk, const uint8_t* sig, const uint8_t* h
   fp12_to_be(ml_out, f);
   *flags_out = flags;
 }
+int hs_g1_codec_roundtrip(const uint8_t* g1, uint8_t* comp32, uint8_t* back64) {
+  bool ok, ok2; G1A p = g1_decode(g1, ok);
+  g1_compress(comp32, p);
+  G1A q = g1_decompress(comp32, ok2);
+  g1_encode(back64, q);
+  return ok && ok2;
+}
+int hs_g2_codec_roundtrip(const uint8_t* g2, uint8_t* comp64, uint8_t* back128) {
+  bool ok, ok2; G2A p = g2_decode(g2, ok);
+  g2_compress(comp64, p);
+  G2A q = g2_decompress(comp64, ok2);
+  g2_encode(back128, q);
+  return ok && ok2;
+}
 void hs_stats(double* out) {
   CheckStats& s = check_stats();
   out[0] = s.worst_mul; out[1] = s.worst_dot; out[2] = s.worst_vb;

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 H = lambda s: int(s, 16)
 ONE_GT = (1).to_bytes(32, "big") + bytes(352)
 IDENT1 = bytes(32) + (1).to_bytes(32, "big")
-IDENT2 = bytes(64) + bytes(31) + b"\x01" + bytes(32)
+IDENT2 = bytes(64) + bytes(32) + bytes(31) + b"\x01"        # x = 0, y = (c1 = 0, c0 = 1): G2Affine::identity, g2.rs
 
 
 @pytest.fixture(scope="module")
@@ -370,3 +370,21 @@ def test_randomized_differential(eng, oracle, pyref, M):
     e1, e2 = b"".join(enc1), b"".join(enc2)
     assert eng.g1_check_batch(e1, 600) == oracle.g1_check_batch(e1, 600)
     assert eng.g2_check_batch(e2, 600) == oracle.g2_check_batch(e2, 600)
+
+
+def test_compressed_codecs_gpu(eng, oracle, pyref, M):
+    rnd = random.Random(12)
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    n = 80
+    p1 = [oracle.g1_mul(G1, rnd.randrange(1, pyref.R)) for _ in range(n - 2)] + [G1, IDENT1]
+    p2 = [oracle.g2_mul(G2, rnd.randrange(1, pyref.R)) for _ in range(n - 2)] + [G2, IDENT2]
+    c1 = eng.g1_compress_batch(b"".join(p1), n); c2 = eng.g2_compress_batch(b"".join(p2), n)
+    assert c1 == b"".join(oracle.g1_compress(p) for p in p1) and c2 == b"".join(oracle.g2_compress(p) for p in p2)
+    assert eng.g1_decompress_batch(c1, n) == b"".join(p1) and eng.g2_decompress_batch(c2, n) == b"".join(p2)
+    x = 1
+    while pyref.fp_sqrt((x ** 3 + 3) % pyref.P) is not None:
+        x += 1
+    with pytest.raises(M.InvalidG1Bytes):
+        eng.g1_decompress_batch(c1[:32] + x.to_bytes(32, "big"), 2)             # no point with that x
+    with pytest.raises(M.InvalidG2Bytes):
+        eng.g2_decompress_batch(b"\x7f" + b"\xff" * 63, 1)                      # coordinate >= p

@@ -111,3 +111,14 @@ def test_hash_checks_and_verify(hs, oracle, pyref, kats):
     assert ml2.raw == ml.raw and fl.value == 3
     assert hs.hs_verify(pk, b"hellp", 5, sig, dst, len(dst), None) == 0
     assert hs.hs_verify(synth.NON_SUBGROUP_PK, msg, len(msg), sig, dst, len(dst), None) == 0
+
+
+def test_compressed_codecs(hs, oracle, pyref):
+    rnd = random.Random(8)
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    c32 = ctypes.create_string_buffer(32); b64 = ctypes.create_string_buffer(64)
+    c64 = ctypes.create_string_buffer(64); b128 = ctypes.create_string_buffer(128)
+    for _ in range(6):
+        p = oracle.g1_mul(G1, rnd.randrange(1, pyref.R)); q = oracle.g2_mul(G2, rnd.randrange(1, pyref.R))
+        assert hs.hs_g1_codec_roundtrip(p, c32, b64) == 1 and b64.raw == p and c32.raw == oracle.g1_compress(p)
+        assert hs.hs_g2_codec_roundtrip(q, c64, b128) == 1 and b128.raw == q and c64.raw == oracle.g2_compress(q)

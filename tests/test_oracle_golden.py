@@ -75,7 +75,7 @@ def test_g2_bad_point_and_identity(oracle, kats):
     # g2.rs:994-1027: bad point is neither on the curve nor torsion free; generator and identity pass
     bp = kats["g2"]["bad_point"]
     bad = bytes.fromhex(bp["x_c1"] + bp["x_c0"] + bp["y_c1"] + bp["y_c0"])
-    ident = bytes(64) + bytes(31) + b"\x01" + bytes(32)          # x = 0, y = 1 (c1 || c0 order)
+    ident = bytes(64) + bytes(32) + bytes(31) + b"\x01"          # x = 0, y = (c1 = 0, c0 = 1)
     pts = bad + oracle.g2_generator() + ident
     assert oracle.g2_check_batch(pts, 3) == bytes([0b110])
     assert oracle.g2_check_batch_slow(pts, 3) == bytes([0b110])
@@ -191,7 +191,7 @@ def test_bls_verify_and_negative_cases(oracle, pyref):
     assert oracle.verify_batch(b"".join(pks), msgs, b"".join(sigs), dst, nthreads=3) == bytes([0b111])
     G1 = oracle.g1_generator()
     ident1 = bytes(32) + (1).to_bytes(32, "big")
-    ident2 = bytes(64) + bytes(31) + b"\x01" + bytes(32)
+    ident2 = bytes(64) + bytes(32) + bytes(31) + b"\x01"
     cases = [
         (pks[0], b"x", sigs[0]),                                   # wrong message
         (pks[1], msgs[0], sigs[0]),                                # wrong key
@@ -234,3 +234,30 @@ def test_aggregate_and_threshold(oracle, pyref):
     with pytest.raises(oracle.OracleError) as e:
         oracle.threshold_combine(idb[:32] * 3, parts, 3)           # duplicate ids
     assert e.value.rc == 1
+
+
+def test_compressed_codecs(oracle, pyref):
+    """Corrected G1 rule (flag = parity of y) round-trips EVERY point, unlike the reference's from_compressed
+    (g1.rs:320, E8); the generator vector of the reference's own round-trip test (g1.rs:938-953) is kept."""
+    rnd = random.Random(6)
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    assert oracle.g1_compress(G1) == (1).to_bytes(32, "big")                    # y = 2 is even: flag clear (g1.rs:956-965)
+    assert oracle.g1_decompress(oracle.g1_compress(G1)) == G1
+    assert oracle.g2_decompress(oracle.g2_compress(G2)) == G2                   # g2.rs:963-978
+    parities = set()
+    for _ in range(20):
+        p = oracle.g1_mul(G1, rnd.randrange(1, pyref.R)); q = oracle.g2_mul(G2, rnd.randrange(1, pyref.R))
+        c = oracle.g1_compress(p)
+        parities.add((c[0] >> 7, int.from_bytes(p[32:], "big") > (pyref.P - 1) // 2))
+        assert oracle.g1_decompress(c) == p and oracle.g2_decompress(oracle.g2_compress(q)) == q
+        x = int.from_bytes(p[:32], "big"); y = int.from_bytes(p[32:], "big")
+        assert (c[0] >> 7) == (y & 1) and int.from_bytes(bytes([c[0] & 0x7f]) + c[1:], "big") == x
+    assert len(parities) >= 3           # (odd,low) / (even,high) points exist in the sample: the cases E8 breaks
+    ident1 = bytes(32) + (1).to_bytes(32, "big")
+    assert oracle.g1_decompress(oracle.g1_compress(ident1)) == ident1
+    assert oracle.g1_decompress(pyref.P.to_bytes(32, "big")) is None            # x >= p
+    # an x with no point on the curve
+    x = 1
+    while pyref.fp_sqrt((x ** 3 + 3) % pyref.P) is not None:
+        x += 1
+    assert oracle.g1_decompress(x.to_bytes(32, "big")) is None
