@@ -36,6 +36,7 @@ struct blsbn254_ctx {
   DevBuf in_a, in_b, in_c, in_off, dst, h_ws, f_ws, f_ws2, flags, sub_ok, status, bitmap, out, scalars, misc;
   DevBuf fe[6];          // final-exponentiation phase buffers (x, a, b, c, b2, d), 108 x n limbs each
   DevBuf inv_ws;         // validated (sig, H, pk) operands of the Miller loop, 72 x n limbs, re-loaded per use
+  DevBuf rlc_a2, rlc_a, rlc_b, rlc_elig, rlc_f2, rlc_bytes, rlc_neg, rlc_ok, rlc_idx, rlc_cpk, rlc_csig, rlc_ch, rlc_csub, rlc_cbm;   // RLC batch verification
   DevBuf fe_slots;       // the ten named powers of the t -> t^x addition chain, 10 x 108 x n limbs
   bool profiling = false;
   std::map<std::string, ProfEntry> prof;
@@ -60,6 +61,14 @@ struct ProfScope {
     hipLaunchKernelGGL(kernel, dim3(nblocks(n)), dim3(256), 0, (ctx)->stream, __VA_ARGS__); } while (0); HIPCHK(ctx, hipGetLastError())
 
 extern "C" {
+
+// -G2gen = (x, p - y) of the generator fp2.rs:305-333, as bytes
+static const uint8_t NEG_G2_BYTES[128] = {
+  0x19,0x8e,0x93,0x93,0x92,0x0d,0x48,0x3a,0x72,0x60,0xbf,0xb7,0x31,0xfb,0x5d,0x25,0xf1,0xaa,0x49,0x33,0x35,0xa9,0xe7,0x12,0x97,0xe4,0x85,0xb7,0xae,0xf3,0x12,0xc2,
+  0x18,0x00,0xde,0xef,0x12,0x1f,0x1e,0x76,0x42,0x6a,0x00,0x66,0x5e,0x5c,0x44,0x79,0x67,0x43,0x22,0xd4,0xf7,0x5e,0xda,0xdd,0x46,0xde,0xbd,0x5c,0xd9,0x92,0xf6,0xed,
+  0x27,0x5d,0xc4,0xa2,0x88,0xd1,0xaf,0xb3,0xcb,0xb1,0xac,0x09,0x18,0x75,0x24,0xc7,0xdb,0x36,0x39,0x5d,0xf7,0xbe,0x3b,0x99,0xe6,0x73,0xb1,0x3a,0x07,0x5a,0x65,0xec,
+  0x1d,0x9b,0xef,0xcd,0x05,0xa5,0x32,0x3e,0x6d,0xa4,0xd4,0x35,0xf3,0xb6,0x17,0xcd,0xb3,0xaf,0x83,0x28,0x5c,0x2d,0xf7,0x11,0xef,0x39,0xc0,0x15,0x71,0x82,0x7f,0x9d};
+
 
 const char* blsbn254_strerror(int code) {
   switch (code) {
@@ -100,6 +109,8 @@ void blsbn254_ctx_destroy(blsbn254_ctx* c) {
   for (DevBuf* b : bufs) b->release();
   for (DevBuf& b : c->fe) b.release();
   c->fe_slots.release(); c->inv_ws.release();
+  { DevBuf* rb[] = {&c->rlc_a2, &c->rlc_a, &c->rlc_b, &c->rlc_elig, &c->rlc_f2, &c->rlc_bytes, &c->rlc_neg, &c->rlc_ok, &c->rlc_idx, &c->rlc_cpk, &c->rlc_csig, &c->rlc_ch, &c->rlc_csub, &c->rlc_cbm};
+    for (DevBuf* b : rb) b->release(); }
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -395,6 +406,88 @@ int blsbn254_verify_batch_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8
   }
   return 0;
 }
+// ---------------- random-linear-combination batch verification
+static const size_t RLC_GROUP = 16;      // tuples per shared final exponentiation (power of two)
+int blsbn254_verify_batch_rlc(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs,
+                              size_t n, const uint8_t* dst, size_t dst_len, const uint8_t seed[32], uint8_t* bm) {
+  if (!c || !off || !seed || (n && (!pks || !sigs || !bm)) || (dst_len && !dst)) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  if (n > ((size_t)1 << 26)) return BLSBN254_E_ARG;                 // one pass; split larger batches in the caller
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
+  if (rc) return rc;
+  rc = stage_msgs(c, msgs, off, n);
+  if (rc) return rc;
+  const size_t G = RLC_GROUP, n_pad = (n + G - 1) / G * G, ng = n_pad / G, nb = (n + 7) / 8;
+  HIPCHK(c, c->in_a.reserve(128 * n)); HIPCHK(c, c->in_b.reserve(64 * n)); HIPCHK(c, c->misc.reserve(64));
+  HIPCHK(c, c->h_ws.reserve(n * 18 * 4)); HIPCHK(c, c->sub_ok.reserve(n)); HIPCHK(c, c->flags.reserve(n_pad));
+  HIPCHK(c, c->rlc_a.reserve(n_pad * 27 * 4)); HIPCHK(c, c->rlc_b.reserve(n_pad * 18 * 4)); HIPCHK(c, c->rlc_elig.reserve(n_pad));
+  HIPCHK(c, c->f_ws.reserve(n_pad * 108 * 4)); HIPCHK(c, c->rlc_f2.reserve(ng * 108 * 4)); HIPCHK(c, c->rlc_bytes.reserve(ng * 64));
+  HIPCHK(c, c->rlc_neg.reserve(ng * 128)); HIPCHK(c, c->rlc_ok.reserve(ng)); HIPCHK(c, c->status.reserve(ng + 8));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->in_b.p, sigs, 64 * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->misc.p, seed, 32, hipMemcpyHostToDevice, c->stream));
+  { std::vector<uint8_t> neg(ng * 128);
+    for (size_t g = 0; g < ng; ++g) std::memcpy(neg.data() + 128 * g, NEG_G2_BYTES, 128);
+    HIPCHK(c, hipMemcpyAsync(c->rlc_neg.p, neg.data(), ng * 128, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream)); }
+  const uint8_t* d_pks = (const uint8_t*)c->in_a.p; const uint8_t* d_sigs = (const uint8_t*)c->in_b.p;
+  int32_t* f = (int32_t*)c->f_ws.p;
+  LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, (uint8_t*)nullptr, 0);
+  LAUNCH(c, "g2_check", k_g2_check, n, d_pks, n, (uint8_t*)c->sub_ok.p, (uint8_t*)nullptr);
+  LAUNCH(c, "rlc_prep", k_rlc_prep, n_pad, d_pks, d_sigs, (const int32_t*)c->h_ws.p, (const uint8_t*)c->sub_ok.p, (const uint8_t*)c->misc.p,
+         n, n_pad, (int32_t*)c->rlc_a.p, (int32_t*)c->rlc_b.p, (uint8_t*)c->rlc_elig.p);
+  // prod_i ML(r_i H_i, pk_i) per group: per-pair loops, ONE where not eligible, log2(G) levels of pairwise products
+  LAUNCH(c, "miller_hpk", k_miller_hpk, n, (const int32_t*)c->rlc_b.p, d_pks, n, f, n_pad, (uint8_t*)c->flags.p);
+  LAUNCH(c, "fp12_mask_one", k_fp12_mask_one, n_pad, f, n_pad, (const uint8_t*)c->rlc_elig.p, n_pad);
+  HIPCHK(c, c->f_ws2.reserve((n_pad / 2) * 108 * 4)); HIPCHK(c, c->rlc_a2.reserve((n_pad / 2) * 27 * 4));
+  int32_t *pa = f, *pb = (int32_t*)c->f_ws2.p, *ga = (int32_t*)c->rlc_a.p, *gb = (int32_t*)c->rlc_a2.p;
+  size_t cnt = n_pad, st = n_pad;
+  for (size_t lvl = 1; lvl < G; lvl <<= 1) {                          // adjacent pairs never straddle a group
+    size_t mo = cnt / 2;
+    LAUNCH(c, "fp12_mul_pairs", k_fp12_mul_pairs, mo, (const int32_t*)pa, cnt, st, pb, mo);
+    LAUNCH(c, "g1_add_pairs", k_g1_add_pairs, mo, (const int32_t*)ga, cnt, st, gb, mo);
+    std::swap(pa, pb); std::swap(ga, gb); st = mo; cnt = mo;
+  }
+  // e(sum_i r_i sig_i, -G2gen) per group, multiplied in; one final exponentiation per group
+  LAUNCH(c, "g1p_to_bytes", k_g1p_to_bytes, ng, (const int32_t*)ga, st, ng, (uint8_t*)c->rlc_bytes.p);
+  LAUNCH(c, "miller_1", k_miller_1, ng, (const uint8_t*)c->rlc_bytes.p, (const uint8_t*)c->rlc_neg.p, ng, (int32_t*)c->rlc_f2.p, ng, (uint8_t*)c->status.p);
+  LAUNCH(c, "fp12_mul_elem", k_fp12_mul_elem, ng, pa, st, (const int32_t*)c->rlc_f2.p, ng, ng);
+  rc = run_final_exp(c, pa, ng, st, 4, nullptr, nullptr, nullptr, (uint8_t*)c->rlc_ok.p, nullptr);
+  if (rc) return rc;
+  std::vector<uint8_t> h_ok(ng), h_elig(n_pad);
+  HIPCHK(c, hipMemcpyAsync(h_ok.data(), c->rlc_ok.p, ng, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_elig.data(), c->rlc_elig.p, n_pad, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memset(bm, 0, nb);
+  std::vector<uint32_t> idx;
+  for (size_t g = 0; g < ng; ++g) {
+    for (size_t i = g * G; i < (g + 1) * G && i < n; ++i) {
+      if (!h_elig[i]) continue;                                        // failed a precheck: invalid, not part of any product
+      if (h_ok[g]) bm[i >> 3] |= (uint8_t)(1u << (i & 7));
+      else idx.push_back((uint32_t)i);
+    }
+  }
+  if (!idx.empty()) {                                                  // exact per-tuple path for the groups that failed
+    size_t m = idx.size(), mb = (m + 7) / 8;
+    HIPCHK(c, c->rlc_idx.reserve(4 * m)); HIPCHK(c, c->rlc_cpk.reserve(128 * m)); HIPCHK(c, c->rlc_csig.reserve(64 * m));
+    HIPCHK(c, c->rlc_ch.reserve(18 * 4 * m)); HIPCHK(c, c->rlc_csub.reserve(m)); HIPCHK(c, c->rlc_cbm.reserve(mb + 8));
+    HIPCHK(c, c->f_ws.reserve(m * 108 * 4)); HIPCHK(c, c->flags.reserve(m)); HIPCHK(c, c->inv_ws.reserve(m * 72 * 4));
+    HIPCHK(c, hipMemcpyAsync(c->rlc_idx.p, idx.data(), 4 * m, hipMemcpyHostToDevice, c->stream));
+    LAUNCH(c, "rlc_gather", k_rlc_gather, m, (const uint32_t*)c->rlc_idx.p, m, d_pks, d_sigs, (const int32_t*)c->h_ws.p, n, (const uint8_t*)c->sub_ok.p,
+           (uint8_t*)c->rlc_cpk.p, (uint8_t*)c->rlc_csig.p, (int32_t*)c->rlc_ch.p, (uint8_t*)c->rlc_csub.p);
+    LAUNCH(c, "miller_verify", k_miller_verify, m, (const uint8_t*)c->rlc_cpk.p, (const uint8_t*)c->rlc_csig.p, (const int32_t*)c->rlc_ch.p, m,
+           (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p, (int32_t*)c->inv_ws.p);
+    rc = run_final_exp(c, (int32_t*)c->f_ws.p, m, m, 0, (const uint8_t*)c->flags.p, (const uint8_t*)c->rlc_csub.p, (uint8_t*)c->rlc_cbm.p, nullptr, nullptr);
+    if (rc) return rc;
+    std::vector<uint8_t> cb(mb);
+    HIPCHK(c, hipMemcpyAsync(cb.data(), c->rlc_cbm.p, mb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (size_t j = 0; j < m; ++j) if (cb[j >> 3] & (1u << (j & 7))) { size_t i = idx[j]; bm[i >> 3] |= (uint8_t)(1u << (i & 7)); }
+  }
+  return 0;
+}
+
 int blsbn254_verify_batch(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs,
                           size_t n, const uint8_t* dst, size_t dst_len, uint8_t* bm) {
   if (!c || !off || (n && (!pks || !sigs || !bm)) || (dst_len && !dst)) return BLSBN254_E_ARG;
@@ -413,13 +506,6 @@ int blsbn254_verify_batch(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* ms
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
-// -G2gen = (x, p - y) of the generator fp2.rs:305-333, as bytes
-static const uint8_t NEG_G2_BYTES[128] = {
-  0x19,0x8e,0x93,0x93,0x92,0x0d,0x48,0x3a,0x72,0x60,0xbf,0xb7,0x31,0xfb,0x5d,0x25,0xf1,0xaa,0x49,0x33,0x35,0xa9,0xe7,0x12,0x97,0xe4,0x85,0xb7,0xae,0xf3,0x12,0xc2,
-  0x18,0x00,0xde,0xef,0x12,0x1f,0x1e,0x76,0x42,0x6a,0x00,0x66,0x5e,0x5c,0x44,0x79,0x67,0x43,0x22,0xd4,0xf7,0x5e,0xda,0xdd,0x46,0xde,0xbd,0x5c,0xd9,0x92,0xf6,0xed,
-  0x27,0x5d,0xc4,0xa2,0x88,0xd1,0xaf,0xb3,0xcb,0xb1,0xac,0x09,0x18,0x75,0x24,0xc7,0xdb,0x36,0x39,0x5d,0xf7,0xbe,0x3b,0x99,0xe6,0x73,0xb1,0x3a,0x07,0x5a,0x65,0xec,
-  0x1d,0x9b,0xef,0xcd,0x05,0xa5,0x32,0x3e,0x6d,0xa4,0xd4,0x35,0xf3,0xb6,0x17,0xcd,0xb3,0xaf,0x83,0x28,0x5c,0x2d,0xf7,0x11,0xef,0x39,0xc0,0x15,0x71,0x82,0x7f,0x9d};
-
 // in-place product tree over `cnt` Fp12 values at a (stride sa); result pointer / stride returned
 static int fp12_tree(blsbn254_ctx* c, int32_t* a, size_t cnt, size_t sa, int32_t** res, size_t* rs) {
   HIPCHK(c, c->f_ws2.reserve(((cnt + 1) / 2) * 108 * 4 + 432));

@@ -27,6 +27,7 @@ BN_KERNEL k_fe_h2(const int32_t* x0, const int32_t* b_in, int32_t* c_out, int32_
   fp12_store_limbs(c_out + i, stride, c); fp12_store_limbs(b2_out + i, stride, b2); fp12_store_limbs(d2_out + i, stride, d2);
 }
 // mode 0: verify -> bitmap bit = flags ok && subgroup ok && result == 1 ; mode 1/2: Gt bytes ; mode 3: *is_one (n == 1)
+// mode 4: gt_bytes[i] = (result == 1) as one byte per element (RLC group check)
 BN_KERNEL k_fe_h3(const int32_t* t, const int32_t* a, const int32_t* c, const int32_t* b2, const int32_t* x0, size_t n, size_t stride,
                   const uint8_t* flags, const uint8_t* sub_ok, uint8_t* bitmap, uint8_t* gt_bytes, int* is_one, int mode) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -36,6 +37,7 @@ BN_KERNEL k_fe_h3(const int32_t* t, const int32_t* a, const int32_t* c, const in
                    fp12_load_limbs(b2 + i, stride), fp12_load_limbs(x0 + i, stride));
     if (mode == 0) bit = fp12_is_one(r) & (flags[i] == (FLAG_SIG_OK | FLAG_PK_OK)) & (sub_ok[i] != 0);
     else if (mode == 3) *is_one = fp12_is_one(r) ? 1 : 0;
+    else if (mode == 4) gt_bytes[i] = fp12_is_one(r) ? 1 : 0;
     else fp12_to_be(gt_bytes + 384 * i, r);
   }
   if (mode == 0) write_ballot(bitmap, n, i, bit);

@@ -35,6 +35,13 @@ BN_KERNEL k_sign(const uint8_t* sks, const uint8_t* msgs, const uint64_t* off, s
 BN_KERNEL k_sk_to_pk(const uint8_t* sks, size_t n, uint8_t* pks, uint8_t* status);
 BN_KERNEL k_g1_codec(const uint8_t* in, size_t n, uint8_t* out, uint8_t* status, int mode);
 BN_KERNEL k_g2_codec(const uint8_t* in, size_t n, uint8_t* out, uint8_t* status, int mode);
+BN_KERNEL k_rlc_prep(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, const uint8_t* sub_ok, const uint8_t* seed,
+                     size_t n, size_t n_pad, int32_t* a_ws, int32_t* b_ws, uint8_t* elig);
+BN_KERNEL k_fp12_mask_one(int32_t* f_ws, size_t stride, const uint8_t* elig, size_t n_pad);
+BN_KERNEL k_fp12_mul_elem(int32_t* a, size_t sa, const int32_t* b, size_t sb, size_t m);
+BN_KERNEL k_g1p_to_bytes(const int32_t* ws, size_t stride, size_t m, uint8_t* out);
+BN_KERNEL k_rlc_gather(const uint32_t* idx, size_t m, const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n,
+                       const uint8_t* sub_ok, uint8_t* c_pks, uint8_t* c_sigs, int32_t* c_h, uint8_t* c_sub);
 BN_KERNEL k_lagrange(const uint8_t* ids, size_t t, uint8_t* scalars, uint8_t* status);
 __global__ void __launch_bounds__(256) k_valu_peak(uint32_t* out, uint32_t seed, int iters);
 __global__ void k_status_reduce(const uint8_t* status, size_t n, uint8_t want_mask, uint8_t want_val, int* first_bad);

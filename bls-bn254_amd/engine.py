@@ -191,6 +191,18 @@ class Engine:
                                                   ctypes.c_size_t(len(dst)), po))
         return o[:(n + 7) // 8].tobytes()
 
+    def verify_batch_rlc(self, pks, msgs, sigs, dst=DEFAULT_DST, seed=None):
+        """Same bitmap as verify_batch, via random linear combinations (one final exponentiation per 16 tuples,
+        exact re-verification of failing groups).  seed: 32 random bytes drawn after the batch is fixed."""
+        n = len(msgs)
+        seed = os.urandom(32) if seed is None else seed
+        data, off = pack_messages(msgs)
+        a, pa = _inbuf(pks, 128 * n); m, pm = _inbuf(data); s, ps = _inbuf(sigs, 64 * n); d, pd = _inbuf(dst); sd, psd = _inbuf(seed, 32)
+        o, po = _outbuf((n + 7) // 8)
+        self._chk(self._lib.blsbn254_verify_batch_rlc(self._ctx, pa, pm, off.ctypes.data_as(_u64p), ps, ctypes.c_size_t(n), pd,
+                                                      ctypes.c_size_t(len(dst)), psd, po))
+        return o[:(n + 7) // 8].tobytes()
+
     def aggregate_verify(self, pks, msgs, agg_sig, dst=DEFAULT_DST):
         n = len(msgs)
         data, off = pack_messages(msgs)

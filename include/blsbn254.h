@@ -99,6 +99,15 @@ int blsbn254_aggregate_verify(blsbn254_ctx* ctx, const uint8_t* pks, const uint8
 int blsbn254_aggregate_partial(blsbn254_ctx* ctx, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
                                const uint8_t* dst, size_t dst_len, uint8_t ml_out[384], int* all_pks_ok);
 int blsbn254_aggregate_finish(blsbn254_ctx* ctx, const uint8_t* partials /* k*384 */, size_t k, const uint8_t agg_sig[64], int* valid);
+/* Same result as blsbn254_verify_batch (same bitmap), computed with random linear combinations (SURVEY.md 8f
+ * rank 4): groups of 16 tuples share ONE final exponentiation,
+ *   prod_i [e(sig_i,-G2gen) e(H_i,pk_i)]^(r_i) = e(sum r_i sig_i, -G2gen) * prod_i e(r_i H_i, pk_i),
+ * with 64-bit r_i = SHA-256(seed || i || pk_i || sig_i); a group whose product is not 1 is re-verified tuple by
+ * tuple with the exact path, so a bit can only differ from verify_batch's with probability 2^-64 per group
+ * (an invalid group passing).  seed: 32 bytes the caller draws at random AFTER the batch is fixed. */
+int blsbn254_verify_batch_rlc(blsbn254_ctx* ctx, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off,
+                              const uint8_t* sigs, size_t n, const uint8_t* dst, size_t dst_len,
+                              const uint8_t seed[32], uint8_t* valid_bitmap);
 /* impl Sum for G1Projective, g1.rs:561-565 */
 int blsbn254_aggregate_sigs(blsbn254_ctx* ctx, const uint8_t* sigs, size_t n, uint8_t out[64]);
 /* sum_i lambda_i * sig_i with Lagrange coefficients at 0 for the t distinct non-zero ids

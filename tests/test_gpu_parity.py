@@ -388,3 +388,30 @@ def test_compressed_codecs_gpu(eng, oracle, pyref, M):
         eng.g1_decompress_batch(c1[:32] + x.to_bytes(32, "big"), 2)             # no point with that x
     with pytest.raises(M.InvalidG2Bytes):
         eng.g2_decompress_batch(b"\x7f" + b"\xff" * 63, 1)                      # coordinate >= p
+
+
+@pytest.mark.parametrize("n,invalid_every", [(1, 0), (15, 0), (16, 3), (17, 0), (1000, 8), (4096, 64), (777, 1)])
+def test_verify_batch_rlc_matches_exact_path(eng, oracle, M, n, invalid_every):
+    """the RLC entry point must return the SAME bitmap as the exact per-tuple path."""
+    dst = M.DEFAULT_DST
+    pks, msgs, sigs, exp = synth.make_batch(oracle, n, dst, invalid_every=invalid_every, uniq=40)
+    want = synth.bitmap_of(exp)
+    assert eng.verify_batch(pks, msgs, sigs, dst) == want
+    assert eng.verify_batch_rlc(pks, msgs, sigs, dst, seed=bytes(range(32))) == want
+    assert eng.verify_batch_rlc(pks, msgs, sigs, dst) == want                       # fresh random seed
+
+
+def test_verify_batch_rlc_adversarial_pairs(eng, oracle, pyref, M):
+    """Two signatures that are individually wrong but whose errors cancel in an UNWEIGHTED product
+    (sig_0 + D, sig_1 - D): the random weights must catch them."""
+    dst = M.DEFAULT_DST
+    sks = [synth.sk_of(k) for k in range(2)]
+    pks = b"".join(oracle.sk_to_pk(s) for s in sks)
+    msgs = [b"a", b"b"]
+    s0, s1 = (oracle.sign(s, m, dst) for s, m in zip(sks, msgs))
+    D = oracle.g1_mul(oracle.g1_generator(), 12345)
+    negD = D[:32] + (pyref.P - int.from_bytes(D[32:], "big")).to_bytes(32, "big")
+    sigs = oracle.g1_add(s0, D) + oracle.g1_add(s1, negD)
+    assert eng.verify_batch(pks, msgs, sigs, dst) == b"\x00"
+    for t in range(4):
+        assert eng.verify_batch_rlc(pks, msgs, sigs, dst, seed=bytes([t]) * 32) == b"\x00"
