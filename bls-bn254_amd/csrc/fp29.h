@@ -426,6 +426,20 @@ BN_FUNC Fp fp_pow(const Fp& a, Exp256 e) {
   }
   return r;
 }
+// Two independent exponentiations with the same public exponent in lockstep: every step issues two
+// independent multiply chains, which hides the dependent-issue latency of a lone square-and-multiply chain.
+BN_FUNC void fp_pow_x2(Fp& r0, Fp& r1, const Fp& a0, const Fp& a1, Exp256 e) {
+  Fp t0[16], t1[16];
+  t0[0] = fp_one(); t1[0] = fp_one();
+  t0[1] = fp_norm(a0); t1[1] = fp_norm(a1);
+  for (int i = 2; i < 16; ++i) { t0[i] = fp_mul(t0[i - 1], t0[1]); t1[i] = fp_mul(t1[i - 1], t1[1]); }
+  r0 = fp_one(); r1 = fp_one();
+  for (int w = 63; w >= 0; --w) {
+    if (w != 63) { for (int q = 0; q < 4; ++q) { r0 = fp_sqr(r0); r1 = fp_sqr(r1); } }
+    int d = (int)((e.w[w >> 4] >> ((w & 15) * 4)) & 15);
+    if (w == 63) { r0 = t0[d]; r1 = t1[d]; } else if (d) { r0 = fp_mul(r0, t0[d]); r1 = fp_mul(r1, t1[d]); }
+  }
+}
 BN_FUNC Fp fp_inv(const Fp& a) { return fp_pow(a, BN_EXP(EXP_PM2)); }                 // inv0(0) = 0 (E15)
 // y = a^((p+1)/4); is_sq = (y^2 == a).  One exponentiation gives Euler's criterion (fp.rs:428-431)
 // and the square root (sqrt_ratio with v = 1, fp.rs:212-243) together.
