@@ -163,6 +163,13 @@ def main():
             out["cpu_baseline"] = {"value": round(sample / cdt, 1), "unit": "verifies/s", "cores": threads, "kind": "port",
                                    "sample": "first %d tuples of the same synthetic workload, C oracle (Montgomery 4x64, "
                                              "oracle/bn254_oracle.c) on %d host threads, %.1f s wall" % (sample, threads, cdt)}
+            # second figure of SURVEY.md 8d: the same workload priced in the reference's own arithmetic (canonical
+            # operands, wide product, bit-serial const_rem_wide, fp.rs:404-407).  An estimate: the measured rate scaled
+            # by the measured cost ratio of the two field multiplies (additions ignored), not a timed verify.
+            ns_ref, ns_mont = O.bench_fp_mul(True, 100000), O.bench_fp_mul(False, 4000000)
+            out["cpu_baseline"]["reference_style_estimate"] = {
+                "value": round(sample / cdt * ns_mont / ns_ref, 2), "unit": "verifies/s", "cores": threads,
+                "fp_mul_ns": {"reference_style": round(ns_ref, 1), "montgomery": round(ns_mont, 1)}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

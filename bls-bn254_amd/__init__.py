@@ -11,4 +11,4 @@ Layout:
   sharded.py   one-process-per-GPU sharding over torch.distributed (RCCL)
 """
 from .engine import (Bn254Error, Engine, InvalidG1Bytes, InvalidG2Bytes, InvalidGtBytes,  # noqa: F401
-                     InvalidScalarBytes, DEFAULT_DST, library_path, load_library)
+                     InvalidScalarBytes, DEFAULT_DST, POP_DST, library_path, load_library)

@@ -48,6 +48,12 @@ BN_INL Fr fr_sub(const Fr& a, const Fr& b) {
   d[NL - 1] = a.l[NL - 1] - b.l[NL - 1] + c;
   return fr_reduce_once(d);
 }
+BN_INL Fr fr_add(const Fr& a, const Fr& b) {
+  int32_t d[NL]; int32_t c = 0;
+  BN_UNROLL for (int i = 0; i < NL - 1; ++i) { int32_t v = a.l[i] + b.l[i] + c; d[i] = v & MASK; c = v >> RB; }
+  d[NL - 1] = a.l[NL - 1] + b.l[NL - 1] + c;
+  return fr_reduce_once(d);
+}
 BN_INL Fr fr_const(const int32_t (&c)[NL]) { Fr r; BN_UNROLL for (int i = 0; i < NL; ++i) r.l[i] = c[i]; return r; }
 BN_INL bool fr_is_zero(const Fr& a) { int32_t o = 0; BN_UNROLL for (int i = 0; i < NL; ++i) o |= a.l[i]; return o == 0; }
 BN_INL Fr fr_select(bool c, const Fr& a, const Fr& b) { Fr r; BN_UNROLL for (int i = 0; i < NL; ++i) r.l[i] = c ? a.l[i] : b.l[i]; return r; }
@@ -70,6 +76,22 @@ BN_INL void fr_to_be(uint8_t* b, const Fr& a) {
   uint32_t w[8];
   limbs_to_words(w, c.l);
   BN_UNROLL for (int j = 0; j < 8; ++j) store_be32(b + 4 * (7 - j), w[j]);
+}
+// 48 big-endian bytes -> OS2IP(okm) mod r in Montgomery form (RFC 9380 hash_to_field with L = 48; the
+// result Scalar::from_okm is meant to produce, scalar.rs:346-352 -- its Reduce<U384>, :393-402, subtracts
+// r only once and truncates, which is not a reduction for 384-bit inputs and is not reproduced).
+// value = lo + hi * 2^261  =>  lo*R + hi*R^2 = mont(lo, R^2) + mont(hi, R^3).
+BN_INL Fr fr_from_okm(const uint8_t* okm) {
+  uint32_t w[12];
+  BN_UNROLL for (int j = 0; j < 12; ++j) w[j] = load_be32(okm + 4 * (11 - j));
+  Fr lo, hi;
+  BN_UNROLL for (int i = 0; i < 2 * NL; ++i) {
+    int bit = RB * i, j = bit >> 5, s = bit & 31;
+    uint32_t v = 0;
+    if (j < 12) { v = w[j] >> s; if (s > 32 - RB && j + 1 < 12) v |= w[j + 1] << (32 - s); }
+    (i < NL ? lo.l[i] : hi.l[i - NL]) = (int32_t)(v & (uint32_t)MASK);
+  }
+  return fr_add(fr_mul(lo, fr_const(bnc::FR_R2)), fr_mul(hi, fr_const(bnc::FR_R3)));
 }
 BN_FUNC Fr fr_inv(const Fr& a) {                 // a^(r-2)
   Fr r = fr_const(bnc::FR_ONE);

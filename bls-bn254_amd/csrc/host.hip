@@ -704,4 +704,78 @@ int blsbn254_sk_to_pk_batch(blsbn254_ctx* c, const uint8_t* sks, size_t n, uint8
   return 0;
 }
 
+// ---------------- key derivation, hash-to-scalar, proof of possession
+int blsbn254_keygen_batch(blsbn254_ctx* c, const uint8_t* ikm, size_t ikm_len, size_t n, const uint8_t* key_info, size_t key_info_len,
+                          uint8_t* sks_out) {
+  if (!c || ikm_len < 32 || (n && (!ikm || !sks_out)) || (key_info_len && !key_info)) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->in_a.reserve(ikm_len * n)); HIPCHK(c, c->in_c.reserve(key_info_len + 1));
+  HIPCHK(c, c->out.reserve(32 * n)); HIPCHK(c, c->status.reserve(n));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, ikm, ikm_len * n, hipMemcpyHostToDevice, c->stream));
+  if (key_info_len) HIPCHK(c, hipMemcpyAsync(c->in_c.p, key_info, key_info_len, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "keygen", k_keygen, n, (const uint8_t*)c->in_a.p, ikm_len, n, (const uint8_t*)c->in_c.p, key_info_len,
+         (uint8_t*)c->out.p, (uint8_t*)c->status.p);
+  int bad; int rc = first_bad(c, (const uint8_t*)c->status.p, n, 1, 1, &bad);
+  if (rc) return rc;
+  if (bad >= 0) return BLSBN254_ERR_SCALAR;
+  HIPCHK(c, hipMemcpyAsync(sks_out, c->out.p, 32 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int blsbn254_hash_to_scalar_batch(blsbn254_ctx* c, const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, size_t dst_len,
+                                  uint8_t* out) {
+  if (!c || !off || (n && (!msgs && off[n] != off[0])) || (n && !out) || (dst_len && !dst)) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
+  if (rc) return rc;
+  rc = stage_msgs(c, msgs, off, n);
+  if (rc) return rc;
+  HIPCHK(c, c->out.reserve(32 * n));
+  LAUNCH(c, "hash_to_scalar", k_hash_to_scalar, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl,
+         (uint8_t*)c->out.p);
+  HIPCHK(c, hipMemcpyAsync(out, c->out.p, 32 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int blsbn254_pop_prove_batch(blsbn254_ctx* c, const uint8_t* sks, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* proofs_out) {
+  if (!c || (n && (!sks || !proofs_out)) || (dst_len && !dst)) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
+  if (rc) return rc;
+  HIPCHK(c, c->in_a.reserve(32 * n)); HIPCHK(c, c->in_c.reserve(128 * n)); HIPCHK(c, c->in_off.reserve(8 * (n + 1)));
+  HIPCHK(c, c->out.reserve(64 * n)); HIPCHK(c, c->status.reserve(n));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, sks, 32 * n, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "sk_to_pk", k_sk_to_pk, n, (const uint8_t*)c->in_a.p, n, (uint8_t*)c->in_c.p, (uint8_t*)c->status.p);
+  LAUNCH(c, "iota_off", k_iota_off, n + 1, (uint64_t*)c->in_off.p, n, (uint64_t)128);
+  LAUNCH(c, "sign", k_sign, n, (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl,
+         (uint8_t*)c->out.p, (uint8_t*)c->status.p);
+  int bad; rc = first_bad(c, (const uint8_t*)c->status.p, n, 1, 1, &bad);
+  if (rc) return rc;
+  if (bad >= 0) return BLSBN254_ERR_SCALAR;
+  HIPCHK(c, hipMemcpyAsync(proofs_out, c->out.p, 64 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int blsbn254_pop_verify_batch(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* proofs, size_t n, const uint8_t* dst, size_t dst_len,
+                              uint8_t* bm) {
+  if (!c || (n && (!pks || !proofs || !bm)) || (dst_len && !dst)) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t nb = (n + 7) / 8;
+  HIPCHK(c, c->in_a.reserve(128 * n)); HIPCHK(c, c->in_b.reserve(64 * n)); HIPCHK(c, c->in_off.reserve(8 * (n + 1)));
+  HIPCHK(c, c->bitmap.reserve(nb + 8));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->in_b.p, proofs, 64 * n, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "iota_off", k_iota_off, n + 1, (uint64_t*)c->in_off.p, n, (uint64_t)128);
+  int rc = blsbn254_verify_batch_dev(c, (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_a.p, (const uint64_t*)c->in_off.p,
+                                     (const uint8_t*)c->in_b.p, n, dst, dst_len, (uint8_t*)c->bitmap.p);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(bm, c->bitmap.p, nb, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 }  // extern "C"

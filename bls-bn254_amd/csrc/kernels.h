@@ -33,6 +33,10 @@ BN_KERNEL k_g1_to_bytes(const int32_t* ws, size_t stride, uint8_t* out);
 BN_KERNEL k_sign(const uint8_t* sks, const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
                  uint8_t* sigs, uint8_t* status);
 BN_KERNEL k_sk_to_pk(const uint8_t* sks, size_t n, uint8_t* pks, uint8_t* status);
+BN_KERNEL k_keygen(const uint8_t* ikm, size_t ikm_len, size_t n, const uint8_t* key_info, size_t key_info_len,
+                   uint8_t* sks, uint8_t* status);
+BN_KERNEL k_hash_to_scalar(const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len, uint8_t* out);
+BN_KERNEL k_iota_off(uint64_t* off, size_t n, uint64_t step);
 BN_KERNEL k_g1_codec(const uint8_t* in, size_t n, uint8_t* out, uint8_t* status, int mode);
 BN_KERNEL k_g2_codec(const uint8_t* in, size_t n, uint8_t* out, uint8_t* status, int mode);
 BN_KERNEL k_rlc_prep(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, const uint8_t* sub_ok, const uint8_t* seed,

@@ -15,6 +15,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_DST = b"BLS_SIG_BN254G1_XMD:SHA-256_SVDW_RO_NUL_"
+POP_DST = b"BLS_POP_BN254G1_XMD:SHA-256_SVDW_RO_POP_"
 _u8p = ctypes.POINTER(ctypes.c_uint8)
 _u64p = ctypes.POINTER(ctypes.c_uint64)
 _lib = None
@@ -262,6 +263,29 @@ class Engine:
         k, pk = _inbuf(sks, 32 * n); o, po = _outbuf(128 * n)
         self._chk(self._lib.blsbn254_sk_to_pk_batch(self._ctx, pk, ctypes.c_size_t(n), po))
         return o[:128 * n].tobytes()
+
+    def keygen_batch(self, ikm, n, key_info=b""):
+        """IETF KeyGen over HKDF-SHA-256 (salt KEYGEN_SALT, helpers.rs:3); ikm = n equal-length seeds >= 32 B."""
+        if n == 0:
+            return b""
+        if len(ikm) % n:
+            raise ValueError("ikm must hold n equal-length seeds")
+        k, pk = _inbuf(ikm); ki, pki = _inbuf(key_info); o, po = _outbuf(32 * n)
+        self._chk(self._lib.blsbn254_keygen_batch(self._ctx, pk, ctypes.c_size_t(len(ikm) // n), ctypes.c_size_t(n), pki,
+                                                  ctypes.c_size_t(len(key_info)), po))
+        return o[:32 * n].tobytes()
+
+    def hash_to_scalar_batch(self, msgs, dst): return self._h2c(self._lib.blsbn254_hash_to_scalar_batch, msgs, dst, 32)
+
+    def pop_prove_batch(self, sks, n, dst=POP_DST):
+        k, pk = _inbuf(sks, 32 * n); d, pd = _inbuf(dst); o, po = _outbuf(64 * n)
+        self._chk(self._lib.blsbn254_pop_prove_batch(self._ctx, pk, ctypes.c_size_t(n), pd, ctypes.c_size_t(len(dst)), po))
+        return o[:64 * n].tobytes()
+
+    def pop_verify_batch(self, pks, proofs, n, dst=POP_DST):
+        a, pa = _inbuf(pks, 128 * n); b, pb = _inbuf(proofs, 64 * n); d, pd = _inbuf(dst); o, po = _outbuf((n + 7) // 8)
+        self._chk(self._lib.blsbn254_pop_verify_batch(self._ctx, pa, pb, ctypes.c_size_t(n), pd, ctypes.c_size_t(len(dst)), po))
+        return o[:(n + 7) // 8].tobytes()
 
     # ---- device-resident variants (raw device pointers, e.g. torch tensor .data_ptr())
     def verify_batch_dev(self, d_pks, d_msgs, d_off, d_sigs, n, d_bitmap, dst=DEFAULT_DST):

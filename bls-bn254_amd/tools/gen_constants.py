@@ -241,6 +241,7 @@ def main():
     s.append("BN_CONST int32_t FR_PINV = %d;     // -r^-1 mod 2^29\n" % ((-pow(RR, -1, 1 << RB)) % (1 << RB)))
     s.append("BN_CONST int32_t FR_ONE[9] = %s;   // R mod r\n" % fmt_limbs(limbs(MONT_R % RR)))
     s.append("BN_CONST int32_t FR_R2[9] = %s;    // R^2 mod r\n" % fmt_limbs(limbs(MONT_R * MONT_R % RR)))
+    s.append("BN_CONST int32_t FR_R3[9] = %s;    // R^3 mod r\n" % fmt_limbs(limbs(pow(MONT_R, 3, RR))))
     s.append("BN_CONST uint64_t EXP_RM2[4] = %s;       // r-2\n" % words(RR - 2))
     s.append("}  // namespace bnc\n\n")
     # fixed-Q line table for -G2gen (the verify equation pairs the signature with -G2gen)

@@ -122,6 +122,24 @@ int blsbn254_sign_batch(blsbn254_ctx* ctx, const uint8_t* sks, const uint8_t* ms
                         const uint8_t* dst, size_t dst_len, uint8_t* sigs_out);
 /* pk_i = [sk_i] G2gen: Mul<Scalar> for G2Projective (g2.rs:866-886) */
 int blsbn254_sk_to_pk_batch(blsbn254_ctx* ctx, const uint8_t* sks, size_t n, uint8_t* pks_out);
+/* sk_i = KeyGen(IKM_i, key_info): IETF BLS KeyGen (draft-irtf-cfrg-bls-signature-05 section 2.3) over
+ * HKDF-SHA-256 with the salt the reference names (KEYGEN_SALT, helpers.rs:3) and L = 48; the reference
+ * has the constant but no procedure.  ikm = n x ikm_len bytes, ikm_len >= 32 (else BLSBN254_E_ARG);
+ * sks_out = n x 32 B big-endian, each in [1, r). */
+int blsbn254_keygen_batch(blsbn254_ctx* ctx, const uint8_t* ikm, size_t ikm_len, size_t n,
+                          const uint8_t* key_info, size_t key_info_len, uint8_t* sks_out);
+/* Scalar::hash<ExpandMsgXmd<Sha256>> (scalar.rs:554-563): OS2IP(expand_message_xmd(msg, dst, 48)) mod r,
+ * out = n x 32 B big-endian.  (The reference's Reduce<U384>, scalar.rs:393-402, subtracts r once and
+ * truncates; the RFC 9380 hash_to_field value it is meant to produce is what is returned here.) */
+int blsbn254_hash_to_scalar_batch(blsbn254_ctx* ctx, const uint8_t* msgs, const uint64_t* off, size_t n,
+                                  const uint8_t* dst, size_t dst_len, uint8_t* out);
+/* Proof of possession (draft section 3.3.2 / 3.3.3): proof_i = [sk_i] H(pk_i bytes) with the 128-byte
+ * uncompressed public key as the message and a caller-supplied POP tag as DST; pop_verify is CoreVerify of
+ * (pk_i, pk_i bytes, proof_i), bitmap as in verify_batch. */
+int blsbn254_pop_prove_batch(blsbn254_ctx* ctx, const uint8_t* sks, size_t n, const uint8_t* dst, size_t dst_len,
+                             uint8_t* proofs_out);
+int blsbn254_pop_verify_batch(blsbn254_ctx* ctx, const uint8_t* pks, const uint8_t* proofs, size_t n,
+                              const uint8_t* dst, size_t dst_len, uint8_t* valid_bitmap);
 
 /* ---- compressed wire codecs ------------------------------------------------- */
 /* G1 32 B: x with bit 255 = parity of y (G1Affine::to_compressed g1.rs:283-288); decompression picks the root

@@ -29,6 +29,7 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 typedef uint64_t u64;
 typedef unsigned __int128 u128;
@@ -564,6 +565,57 @@ static void sha256_final(sha256_ctx* c, uint8_t out[32]) {
   sha256_update(c, len, 8);
   for (int i = 0; i < 8; ++i) { out[4 * i] = (uint8_t)(c->h[i] >> 24); out[4 * i + 1] = (uint8_t)(c->h[i] >> 16); out[4 * i + 2] = (uint8_t)(c->h[i] >> 8); out[4 * i + 3] = (uint8_t)c->h[i]; }
 }
+static void oracle_ensure_init(void);
+/* ---- the reference's own cost model, for the CPU baseline's second figure --------------
+ * Fp::multiply (fp.rs:404-407) keeps canonical operands, forms the 512-bit product (U256::mul_wide) and
+ * reduces it with crypto-bigint 0.5.5's U256::const_rem_wide: the modulus is shifted up by 512 - 254 bits
+ * and then 259 rounds of {8-limb subtract with borrow, select on the borrow, shift the divisor right by
+ * one bit} follow.  Restated here from that published algorithm; timed, never used for results. */
+static void refstyle_mul(u64 r[4], const u64 a[4], const u64 b[4], const u64 m[4], int mbits) {
+  u64 t[8] = {0};
+  for (int i = 0; i < 4; ++i) {
+    u64 carry = 0;
+    for (int j = 0; j < 4; ++j) { u128 v = (u128)a[i] * b[j] + t[i + j] + carry; t[i + j] = (u64)v; carry = (u64)(v >> 64); }
+    t[i + 4] = carry;
+  }
+  int bd = 512 - mbits;
+  u64 c[8] = {0};
+  int ws = bd >> 6, bs = bd & 63;
+  for (int i = 0; i < 4; ++i) {
+    c[i + ws] |= m[i] << bs;
+    if (bs && i + ws + 1 < 8) c[i + ws + 1] |= m[i] >> (64 - bs);
+  }
+  for (;;) {
+    u64 s[8], borrow = 0;
+    for (int i = 0; i < 8; ++i) { u128 d = (u128)t[i] - c[i] - borrow; s[i] = (u64)d; borrow = (u64)(d >> 64) & 1; }
+    u64 keep = (u64)0 - borrow;                       /* all ones: the subtraction underflowed, keep t */
+    for (int i = 0; i < 8; ++i) t[i] = (t[i] & keep) | (s[i] & ~keep);
+    if (bd == 0) break;
+    --bd;
+    for (int i = 0; i < 7; ++i) c[i] = (c[i] >> 1) | (c[i + 1] << 63);
+    c[7] >>= 1;
+  }
+  for (int i = 0; i < 4; ++i) r[i] = t[i];
+}
+void oracle_fp_mul_refstyle(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]) {
+  u64 x[4], y[4], z[4];
+  be32_to_limbs(x, a); be32_to_limbs(y, b);
+  refstyle_mul(z, x, y, P_LIMBS, 254);
+  limbs_to_be32(out, z);
+}
+/* ns per field multiplication over a dependent chain of `iters` products; refstyle != 0 selects the restated
+ * reference arithmetic, 0 the Montgomery multiply every oracle result is computed with */
+double oracle_bench_fp_mul(int refstyle, uint64_t iters) {
+  oracle_ensure_init();
+  u64 x[4] = {0x123456789abcdef1ULL, 0x0fedcba987654321ULL, 0x1111111122222222ULL, 0x0123456701234567ULL}, y[4];
+  memcpy(y, x, 32); y[0] ^= 0x5555;
+  struct timespec t0, t1;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (u64 i = 0; i < iters; ++i) { if (refstyle) refstyle_mul(x, x, y, P_LIMBS, 254); else mont_mul(x, x, y, &FP); }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  volatile u64 sink = x[0]; (void)sink;
+  return ((double)(t1.tv_sec - t0.tv_sec) * 1e9 + (double)(t1.tv_nsec - t0.tv_nsec)) / (double)iters;
+}
 void oracle_sha256(const uint8_t* msg, size_t len, uint8_t out[32]) { sha256_ctx c; sha256_init(&c); sha256_update(&c, msg, len); sha256_final(&c, out); }
 
 /* RFC 9380 5.3.1; the reference calls elliptic-curve's ExpandMsgXmd<Sha256> (fp.rs:440, fp2.rs:470) */
@@ -840,6 +892,7 @@ static void init_impl(void) {
   ATE_NAF_LEN = n;
 }
 static void init(void) { pthread_once(&once, init_impl); }
+static void oracle_ensure_init(void) { init(); }
 
 /* ================================================================== exported entry points */
 void oracle_g1_generator(uint8_t out[64]) { init(); g1a g = {fp_from_u64(1), fp_from_u64(2), 0}; g1_encode(out, g); }

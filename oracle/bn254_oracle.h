@@ -70,6 +70,9 @@ int oracle_g1_decompress(const uint8_t in[32], uint8_t out[64]);
 int oracle_g2_compress(const uint8_t in[128], uint8_t out[64]);
 int oracle_g2_decompress(const uint8_t in[64], uint8_t out[128]);
 void oracle_sha256(const uint8_t* msg, size_t len, uint8_t out[32]);
+/* the reference's canonical-form multiply (fp.rs:404-407 over crypto-bigint's const_rem_wide), for timing only */
+void oracle_fp_mul_refstyle(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
+double oracle_bench_fp_mul(int refstyle, uint64_t iters);
 
 /* instrumentation: exact Fp multiplication / squaring counts of the calling thread */
 void oracle_verify_core_counts(uint64_t out[4]);

@@ -246,3 +246,14 @@ def g1_compress(pt): return _codec(lib().oracle_g1_compress, pt, 64, 32)
 def g1_decompress(c): return _codec(lib().oracle_g1_decompress, c, 32, 64)
 def g2_compress(pt): return _codec(lib().oracle_g2_compress, pt, 128, 64)
 def g2_decompress(c): return _codec(lib().oracle_g2_decompress, c, 64, 128)
+
+
+def fp_mul_refstyle(a, b):
+    """Fp::multiply as the reference computes it (fp.rs:404-407 over const_rem_wide); timing aid only."""
+    x, px = _buf(a.to_bytes(32, "big")); y, py = _buf(b.to_bytes(32, "big")); o, po = _out(32)
+    lib().oracle_fp_mul_refstyle(px, py, po); return int.from_bytes(o.tobytes(), "big")
+
+
+def bench_fp_mul(refstyle, iters):
+    f = lib().oracle_bench_fp_mul; f.restype = ctypes.c_double
+    return f(ctypes.c_int(1 if refstyle else 0), ctypes.c_uint64(iters))

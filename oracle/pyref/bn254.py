@@ -511,6 +511,33 @@ def sk_to_pk(sk): return g2_mul(G2_GEN, sk % R)
 def sign(sk, msg, dst=DEFAULT_DST): return g1_mul(hash_to_g1(msg, dst), sk % R)
 
 
+POP_DST = b"BLS_POP_BN254G1_XMD:SHA-256_SVDW_RO_POP_"
+KEYGEN_SALT = b"BLS-SIG-KEYGEN-SALT-"          # helpers.rs:3
+
+
+def hash_to_scalar(msg, dst):        # Scalar::hash, scalar.rs:554-563, with the reduction from_okm is meant to do
+    return int.from_bytes(expand_message_xmd(msg, dst, 48), "big") % R
+
+
+def keygen(ikm, key_info=b""):       # draft-irtf-cfrg-bls-signature-05 section 2.3, HKDF from the stdlib hmac
+    import hmac
+    assert len(ikm) >= 32
+    salt, L = KEYGEN_SALT, 48
+    while True:
+        salt = hashlib.sha256(salt).digest()
+        prk = hmac.new(salt, ikm + b"\x00", hashlib.sha256).digest()
+        info = key_info + L.to_bytes(2, "big")
+        t1 = hmac.new(prk, info + b"\x01", hashlib.sha256).digest()
+        t2 = hmac.new(prk, t1 + info + b"\x02", hashlib.sha256).digest()
+        sk = int.from_bytes((t1 + t2)[:L], "big") % R
+        if sk:
+            return sk
+
+
+def pop_prove(sk, dst=POP_DST): return sign(sk, g2_to_bytes(sk_to_pk(sk)), dst)
+def pop_verify_bytes(pk_b, proof_b, dst=POP_DST): return verify_bytes(pk_b, pk_b, proof_b, dst)
+
+
 def verify_bytes(pk_b, msg, sig_b, dst=DEFAULT_DST):
     ok, sig = g1_from_bytes(sig_b)
     if not ok or sig is None or not g1_on_curve(sig):

@@ -6,6 +6,7 @@
 #define BN_WANT_LINE_TABLE
 #define BN_LINE_TABLE_QUAL static const
 #include "../../bls-bn254_amd/csrc/lane_ops.h"
+#include "../../bls-bn254_amd/csrc/keygen.h"
 #include <cstring>
 
 using namespace bn;
@@ -28,6 +29,13 @@ void hs_fp_mix(const uint8_t* a, const uint8_t* b, uint8_t* out) {
 }
 int hs_fp_decode_ok(const uint8_t* a) { bool o; (void)fp_from_be(a, o); return o; }
 void hs_fp_from_okm(const uint8_t* okm, uint8_t* out) { fp_to_be(out, fp_from_okm(okm)); }
+void hs_fr_from_okm(const uint8_t* okm, uint8_t* out) { fr_to_be(out, fr_from_okm(okm)); }
+int hs_keygen(const uint8_t* ikm, size_t ikm_len, const uint8_t* info, size_t info_len, uint8_t* out) {
+  bool ok; Fr sk = lane_keygen(ikm, ikm_len, info, info_len, ok); fr_to_be(out, sk); return ok;
+}
+void hs_hash_to_scalar(const uint8_t* msg, size_t len, const uint8_t* dst, uint32_t dst_len, uint8_t* out) {
+  fr_to_be(out, lane_hash_to_scalar(msg, len, dst, dst_len));
+}
 
 void hs_miller1(const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* status) {
   uint8_t st;

@@ -122,3 +122,21 @@ def test_compressed_codecs(hs, oracle, pyref):
         p = oracle.g1_mul(G1, rnd.randrange(1, pyref.R)); q = oracle.g2_mul(G2, rnd.randrange(1, pyref.R))
         assert hs.hs_g1_codec_roundtrip(p, c32, b64) == 1 and b64.raw == p and c32.raw == oracle.g1_compress(p)
         assert hs.hs_g2_codec_roundtrip(q, c64, b128) == 1 and b128.raw == q and c64.raw == oracle.g2_compress(q)
+
+
+def test_keygen_and_hash_to_scalar(hs, pyref):
+    """HMAC / HKDF / XMD-to-scalar device code against the stdlib hmac + big-int restatement."""
+    rnd = random.Random(7)
+    out = ctypes.create_string_buffer(32)
+    for okm in [bytes(48), b"\xff" * 48, (pyref.R).to_bytes(48, "big"), (pyref.R - 1).to_bytes(48, "big"),
+                (2 * pyref.R + 5).to_bytes(48, "big")] + [rnd.randbytes(48) for _ in range(20)]:
+        hs.hs_fr_from_okm(okm, out)
+        assert int.from_bytes(out.raw, "big") == int.from_bytes(okm, "big") % pyref.R
+    for ikm_len, info in ((32, b""), (32, b"key info"), (33, b"x" * 70), (64, b""), (100, b"abc")):
+        ikm = rnd.randbytes(ikm_len)
+        assert hs.hs_keygen(ikm, ctypes.c_size_t(ikm_len), info, ctypes.c_size_t(len(info)), out) == 1
+        assert int.from_bytes(out.raw, "big") == pyref.keygen(ikm, info)
+    dst = b"QUUX-V01-CS02-with-BN254FR_XMD:SHA-256"
+    for msg in (b"", b"abc", rnd.randbytes(200)):
+        hs.hs_hash_to_scalar(msg, ctypes.c_size_t(len(msg)), dst, len(dst), out)
+        assert int.from_bytes(out.raw, "big") == pyref.hash_to_scalar(msg, dst)

@@ -261,3 +261,13 @@ def test_compressed_codecs(oracle, pyref):
     while pyref.fp_sqrt((x ** 3 + 3) % pyref.P) is not None:
         x += 1
     assert oracle.g1_decompress(x.to_bytes(32, "big")) is None
+
+
+def test_reference_style_multiply(oracle, pyref):
+    """The timing-only restatement of Fp::multiply (fp.rs:404-407, wide product + const_rem_wide) is a correct
+    multiply, so the cost ratio bench.py reports is between two implementations of the same function."""
+    rnd = random.Random(9)
+    P = pyref.P
+    for a, b in [(0, 0), (1, P - 1), (P - 1, P - 1), (2**253, 2**253)] + [(rnd.randrange(P), rnd.randrange(P)) for _ in range(100)]:
+        assert oracle.fp_mul_refstyle(a, b) == a * b % P
+    assert oracle.bench_fp_mul(True, 1000) > 0 and oracle.bench_fp_mul(False, 1000) > 0
