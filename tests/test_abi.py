@@ -30,6 +30,20 @@ def test_header_declares_the_surveyed_entry_points():
         assert want in syms
 
 
+def test_rust_shim_extern_block_matches_the_header():
+    """integration/rust/ffi.rs is generated from include/blsbn254.h; the committed copy must be current and must
+    declare every entry point exactly once (the reference-side binding)."""
+    import subprocess
+    import sys
+    gen = os.path.join(ROOT, "integration", "rust", "gen_ffi.py")
+    assert subprocess.call([sys.executable, gen, "--check"]) == 0, "run python integration/rust/gen_ffi.py"
+    ffi = open(os.path.join(ROOT, "integration", "rust", "ffi.rs")).read()
+    assert sorted(re.findall(r"pub fn (blsbn254_[a-z0-9_]+)\(", ffi)) == declared_symbols()
+    shim = open(os.path.join(ROOT, "integration", "rust", "gpu.rs")).read()
+    for used in set(re.findall(r"ffi::(blsbn254_[a-z0-9_]+)", shim)):
+        assert used in declared_symbols()
+
+
 def test_library_exports_every_declared_symbol(M):
     path = M.library_path()
     if not os.path.exists(path):
