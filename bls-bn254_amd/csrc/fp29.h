@@ -40,6 +40,12 @@
 #endif
 
 #define BN_UNROLL _Pragma("unroll")
+// nothing is scheduled across this point (device only): used to keep a prefetch above the work that hides it
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BN_SCHED_BARRIER __builtin_amdgcn_sched_barrier(0)
+#else
+#define BN_SCHED_BARRIER ((void)0)
+#endif
 
 #ifdef BN_CHECK
 #include <cmath>
@@ -418,27 +424,19 @@ BN_FUNC Fp fp_pow(const Fp& a, Exp256 e) {
   tab[0] = fp_one();
   tab[1] = fp_norm(a);
   for (int i = 2; i < 16; ++i) tab[i] = fp_mul(tab[i - 1], tab[1]);
-  Fp r = fp_one();
-  for (int w = 63; w >= 0; --w) {
-    if (w != 63) { r = fp_sqr(r); r = fp_sqr(r); r = fp_sqr(r); r = fp_sqr(r); }
-    int d = (int)((e.w[w >> 4] >> ((w & 15) * 4)) & 15);
-    if (w == 63) r = tab[d]; else if (d) r = fp_mul(r, tab[d]);
+  const uint64_t e0 = e.w[0], e1 = e.w[1], e2 = e.w[2], e3 = e.w[3];   // wave-uniform: stay in scalar registers
+  Fp r = tab[(int)(e3 >> 60)];
+  for (int w = 62; w >= 0; --w) {
+    uint64_t word = w >= 48 ? e3 : w >= 32 ? e2 : w >= 16 ? e1 : e0;
+    int d = (int)((word >> ((w & 15) * 4)) & 15);
+    // The table lives in scratch.  Its entry is fetched before the four squarings, and the barrier keeps the
+    // loads there, so their latency is hidden; multiplying unconditionally (tab[0] = 1) keeps the use in this block.
+    Fp t = tab[d];
+    BN_SCHED_BARRIER;
+    r = fp_sqr(r); r = fp_sqr(r); r = fp_sqr(r); r = fp_sqr(r);
+    r = fp_mul(r, t);
   }
   return r;
-}
-// Two independent exponentiations with the same public exponent in lockstep: every step issues two
-// independent multiply chains, which hides the dependent-issue latency of a lone square-and-multiply chain.
-BN_FUNC void fp_pow_x2(Fp& r0, Fp& r1, const Fp& a0, const Fp& a1, Exp256 e) {
-  Fp t0[16], t1[16];
-  t0[0] = fp_one(); t1[0] = fp_one();
-  t0[1] = fp_norm(a0); t1[1] = fp_norm(a1);
-  for (int i = 2; i < 16; ++i) { t0[i] = fp_mul(t0[i - 1], t0[1]); t1[i] = fp_mul(t1[i - 1], t1[1]); }
-  r0 = fp_one(); r1 = fp_one();
-  for (int w = 63; w >= 0; --w) {
-    if (w != 63) { for (int q = 0; q < 4; ++q) { r0 = fp_sqr(r0); r1 = fp_sqr(r1); } }
-    int d = (int)((e.w[w >> 4] >> ((w & 15) * 4)) & 15);
-    if (w == 63) { r0 = t0[d]; r1 = t1[d]; } else if (d) { r0 = fp_mul(r0, t0[d]); r1 = fp_mul(r1, t1[d]); }
-  }
 }
 BN_FUNC Fp fp_inv(const Fp& a) { return fp_pow(a, BN_EXP(EXP_PM2)); }                 // inv0(0) = 0 (E15)
 // y = a^((p+1)/4); is_sq = (y^2 == a).  One exponentiation gives Euler's criterion (fp.rs:428-431)

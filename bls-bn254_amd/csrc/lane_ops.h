@@ -71,10 +71,8 @@ BN_FUNC Fp12 lane_miller_1(const uint8_t* g1, const uint8_t* g2, const int8_t* n
   q.x = fp2_select(bad, gq.x, q.x); q.y = fp2_select(bad, gq.y, q.y);
   Fp12 f = miller_loop_1(p, q, naf, naf_len);
   Fp12 one = fp12_one();
-  // select limb-wise
-  Fp2* fs[6] = {&f.c0.c0, &f.c0.c1, &f.c0.c2, &f.c1.c0, &f.c1.c1, &f.c1.c2};
-  const Fp2* os[6] = {&one.c0.c0, &one.c0.c1, &one.c0.c2, &one.c1.c0, &one.c1.c1, &one.c1.c2};
-  for (int i = 0; i < 6; ++i) *fs[i] = fp2_select(bad, *os[i], *fs[i]);
+  f.c0 = {fp2_select(bad, one.c0.c0, f.c0.c0), fp2_select(bad, one.c0.c1, f.c0.c1), fp2_select(bad, one.c0.c2, f.c0.c2)};
+  f.c1 = {fp2_select(bad, one.c1.c0, f.c1.c0), fp2_select(bad, one.c1.c1, f.c1.c1), fp2_select(bad, one.c1.c2, f.c1.c2)};
   return f;
 }
 // verify: f = ML(sig, -G2gen) * ML(H, pk); flags = FLAG_SIG_OK | FLAG_PK_OK when decodable, on curve, non-identity

@@ -257,41 +257,50 @@ BN_FUNC Fp12 final_exponentiation(const Fp12& f) {
 }
 
 // Gt byte layout (Gt::to_repr / from_repr, pairings.rs:499-579): c0.c0.c0, c0.c0.c1, c0.c1.c0, ...
+// The six Fp2 components are named one by one below, never reached through an array of pointers: an index
+// the compiler cannot resolve would force the whole Fp12 -- the accumulator of the caller's main loop -- to
+// live in scratch memory instead of registers.
+BN_INL void fp2_to_be(uint8_t* out, const Fp2& c) { fp_to_be(out, c.c0); fp_to_be(out + 32, c.c1); }
 BN_FUNC void fp12_to_be(uint8_t* out, const Fp12& a) {
   BN_CTX;
-  const Fp2* s[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
-  for (int i = 0; i < 6; ++i) { fp_to_be(out + 64 * i, s[i]->c0); fp_to_be(out + 64 * i + 32, s[i]->c1); }
+  fp2_to_be(out, a.c0.c0); fp2_to_be(out + 64, a.c0.c1); fp2_to_be(out + 128, a.c0.c2);
+  fp2_to_be(out + 192, a.c1.c0); fp2_to_be(out + 256, a.c1.c1); fp2_to_be(out + 320, a.c1.c2);
+}
+BN_INL Fp2 fp2_from_be(const uint8_t* in, bool& ok) {
+  bool o0, o1;
+  Fp2 c = {fp_from_be(in, o0), fp_from_be(in + 32, o1)};
+  ok &= o0 & o1;
+  return c;
 }
 BN_FUNC Fp12 fp12_from_be(const uint8_t* in, bool& ok) {
   BN_CTX;
-  Fp12 a;
-  Fp2* s[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
   ok = true;
-  for (int i = 0; i < 6; ++i) {
-    bool o0, o1;
-    s[i]->c0 = fp_from_be(in + 64 * i, o0); s[i]->c1 = fp_from_be(in + 64 * i + 32, o1);
-    ok &= o0 & o1;
-  }
+  Fp12 a;
+  a.c0.c0 = fp2_from_be(in, ok); a.c0.c1 = fp2_from_be(in + 64, ok); a.c0.c2 = fp2_from_be(in + 128, ok);
+  a.c1.c0 = fp2_from_be(in + 192, ok); a.c1.c1 = fp2_from_be(in + 256, ok); a.c1.c2 = fp2_from_be(in + 320, ok);
   return a;
 }
 // Device-side workspace form of an Fp12: 108 strict limbs (canonical Montgomery), c0.c0.c0 first.
+BN_INL void fp2_store_limbs(int32_t* out, size_t stride, const Fp2& c) {
+  Fp c0 = fp_canon(c.c0), c1 = fp_canon(c.c1);
+  BN_UNROLL for (int k = 0; k < NL; ++k) { out[(size_t)k * stride] = c0.l[k]; out[(size_t)(9 + k) * stride] = c1.l[k]; }
+}
 BN_FUNC void fp12_store_limbs(int32_t* out, size_t stride, const Fp12& a) {
   BN_CTX;
-  const Fp2* s[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
-  for (int i = 0; i < 6; ++i) {
-    Fp c0 = fp_canon(s[i]->c0), c1 = fp_canon(s[i]->c1);
-    for (int k = 0; k < NL; ++k) { out[(size_t)(18 * i + k) * stride] = c0.l[k]; out[(size_t)(18 * i + 9 + k) * stride] = c1.l[k]; }
-  }
+  fp2_store_limbs(out, stride, a.c0.c0); fp2_store_limbs(out + 18 * stride, stride, a.c0.c1);
+  fp2_store_limbs(out + 36 * stride, stride, a.c0.c2); fp2_store_limbs(out + 54 * stride, stride, a.c1.c0);
+  fp2_store_limbs(out + 72 * stride, stride, a.c1.c1); fp2_store_limbs(out + 90 * stride, stride, a.c1.c2);
+}
+BN_INL Fp2 fp2_load_limbs(const int32_t* in, size_t stride) {
+  Fp2 c;
+  BN_UNROLL for (int k = 0; k < NL; ++k) { c.c0.l[k] = in[(size_t)k * stride]; c.c1.l[k] = in[(size_t)(9 + k) * stride]; }
+  BN_TRK(set_trk(c.c0, 0, 1, 0, 0.006, 1); set_trk(c.c1, 0, 1, 0, 0.006, 1);)
+  return c;
 }
 BN_FUNC Fp12 fp12_load_limbs(const int32_t* in, size_t stride) {
   BN_CTX;
-  Fp12 a;
-  Fp2* s[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
-  for (int i = 0; i < 6; ++i) {
-    for (int k = 0; k < NL; ++k) { s[i]->c0.l[k] = in[(size_t)(18 * i + k) * stride]; s[i]->c1.l[k] = in[(size_t)(18 * i + 9 + k) * stride]; }
-    BN_TRK(set_trk(s[i]->c0, 0, 1, 0, 0.006, 1); set_trk(s[i]->c1, 0, 1, 0, 0.006, 1);)
-  }
-  return a;
+  return {{fp2_load_limbs(in, stride), fp2_load_limbs(in + 18 * stride, stride), fp2_load_limbs(in + 36 * stride, stride)},
+          {fp2_load_limbs(in + 54 * stride, stride), fp2_load_limbs(in + 72 * stride, stride), fp2_load_limbs(in + 90 * stride, stride)}};
 }
 
 }  // namespace bn

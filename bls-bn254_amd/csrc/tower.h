@@ -211,23 +211,23 @@ BN_FUNC Fp12 fp12_mul_by_034(const Fp12& f, const Fp2& o0, const Fp2& o3, const 
   return {fp6_add_mul_v(a, b), fp6_norm(fp6_sub(fp6_sub(e, a), b))};
 }
 // Frobenius^k, k = 1..3: coefficient of w^i -> conj^k(.) * xi^(i (p^k-1)/6)   (E3 fixed)
+template <int K, int I>
+BN_INL Fp2 fp12_frob_coeff(const Fp2& in) {                     // coefficient of w^I
+  Fp2 c = in;
+  if (K & 1) c = fp2_norm(fp2_conj(c));
+  if (I > 0) {
+    if (K == 1) c = fp2_mul(c, fp2_const(bnc::GAMMA1[I - 1]));
+    if (K == 2) c = fp2_mul_fp(c, fp_const(bnc::GAMMA2[I - 1]));
+    if (K == 3) c = fp2_mul(c, fp2_const(bnc::GAMMA3[I - 1]));
+  }
+  return c;
+}
 template <int K>
 BN_FUNC Fp12 fp12_frob(const Fp12& a) {
   BN_CTX;
   // tower slot -> w index: c0.c0=0 c1.c0=1 c0.c1=2 c1.c1=3 c0.c2=4 c1.c2=5
-  const Fp2* s[6] = {&a.c0.c0, &a.c1.c0, &a.c0.c1, &a.c1.c1, &a.c0.c2, &a.c1.c2};
-  Fp2 o[6];
-  BN_UNROLL for (int i = 0; i < 6; ++i) {
-    Fp2 c = *s[i];
-    if (K & 1) c = fp2_norm(fp2_conj(c));
-    if (i > 0) {
-      if (K == 1) c = fp2_mul(c, fp2_const(bnc::GAMMA1[i - 1]));
-      if (K == 2) c = fp2_mul_fp(c, fp_const(bnc::GAMMA2[i - 1]));
-      if (K == 3) c = fp2_mul(c, fp2_const(bnc::GAMMA3[i - 1]));
-    }
-    o[i] = c;
-  }
-  return {{o[0], o[2], o[4]}, {o[1], o[3], o[5]}};
+  return {{fp12_frob_coeff<K, 0>(a.c0.c0), fp12_frob_coeff<K, 2>(a.c0.c1), fp12_frob_coeff<K, 4>(a.c0.c2)},
+          {fp12_frob_coeff<K, 1>(a.c1.c0), fp12_frob_coeff<K, 3>(a.c1.c1), fp12_frob_coeff<K, 5>(a.c1.c2)}};
 }
 BN_INL void fp4_square(Fp2& c0, Fp2& c1, const Fp2& a, const Fp2& b) {      // pairings.rs:52-63
   Fp2 t0 = fp2_sqr(a), t1 = fp2_sqr(b);
