@@ -35,7 +35,6 @@ struct blsbn254_ctx {
   hipStream_t stream = nullptr;
   DevBuf in_a, in_b, in_c, in_off, dst, h_ws, f_ws, f_ws2, flags, sub_ok, status, bitmap, out, scalars, misc;
   DevBuf fe[6];          // final-exponentiation phase buffers (x, a, b, c, b2, d), 108 x n limbs each
-  DevBuf inv_ws;         // validated (sig, H, pk) operands of the Miller loop, 72 x n limbs, re-loaded per use
   DevBuf rlc_a2, rlc_a, rlc_b, rlc_elig, rlc_f2, rlc_bytes, rlc_neg, rlc_ok, rlc_idx, rlc_cpk, rlc_csig, rlc_ch, rlc_csub, rlc_cbm;   // RLC batch verification
   DevBuf fe_slots;       // the ten named powers of the t -> t^x addition chain, 10 x 108 x n limbs
   bool profiling = false;
@@ -108,7 +107,7 @@ void blsbn254_ctx_destroy(blsbn254_ctx* c) {
   DevBuf* bufs[] = {&c->in_a, &c->in_b, &c->in_c, &c->in_off, &c->dst, &c->h_ws, &c->f_ws, &c->f_ws2, &c->flags, &c->sub_ok, &c->status, &c->bitmap, &c->out, &c->scalars, &c->misc};
   for (DevBuf* b : bufs) b->release();
   for (DevBuf& b : c->fe) b.release();
-  c->fe_slots.release(); c->inv_ws.release();
+  c->fe_slots.release();
   { DevBuf* rb[] = {&c->rlc_a2, &c->rlc_a, &c->rlc_b, &c->rlc_elig, &c->rlc_f2, &c->rlc_bytes, &c->rlc_neg, &c->rlc_ok, &c->rlc_idx, &c->rlc_cpk, &c->rlc_csig, &c->rlc_ch, &c->rlc_csub, &c->rlc_cbm};
     for (DevBuf* b : rb) b->release(); }
   (void)hipStreamDestroy(c->stream);
@@ -386,10 +385,10 @@ static const size_t VERIFY_CHUNK = (size_t)1 << 22;
 static int verify_chunk_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
                             const uint8_t* d_sigs, size_t n, uint32_t dl, uint8_t* d_bitmap) {
   HIPCHK(c, c->h_ws.reserve(n * 18 * 4)); HIPCHK(c, c->f_ws.reserve(n * 108 * 4));
-  HIPCHK(c, c->flags.reserve(n)); HIPCHK(c, c->sub_ok.reserve(n)); HIPCHK(c, c->inv_ws.reserve(n * 72 * 4));
+  HIPCHK(c, c->flags.reserve(n)); HIPCHK(c, c->sub_ok.reserve(n));
   LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, d_msgs, d_off, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, (uint8_t*)nullptr, 0);
   LAUNCH(c, "g2_check", k_g2_check, n, d_pks, n, (uint8_t*)c->sub_ok.p, (uint8_t*)nullptr);
-  LAUNCH(c, "miller_verify", k_miller_verify, n, d_pks, d_sigs, (const int32_t*)c->h_ws.p, n, (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p, (int32_t*)c->inv_ws.p);
+  LAUNCH(c, "miller_verify", k_miller_verify, n, d_pks, d_sigs, (const int32_t*)c->h_ws.p, n, (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
   return run_final_exp(c, (int32_t*)c->f_ws.p, n, n, 0, (const uint8_t*)c->flags.p, (const uint8_t*)c->sub_ok.p, d_bitmap, nullptr, nullptr);
 }
 int blsbn254_verify_batch_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
@@ -472,12 +471,12 @@ int blsbn254_verify_batch_rlc(blsbn254_ctx* c, const uint8_t* pks, const uint8_t
     size_t m = idx.size(), mb = (m + 7) / 8;
     HIPCHK(c, c->rlc_idx.reserve(4 * m)); HIPCHK(c, c->rlc_cpk.reserve(128 * m)); HIPCHK(c, c->rlc_csig.reserve(64 * m));
     HIPCHK(c, c->rlc_ch.reserve(18 * 4 * m)); HIPCHK(c, c->rlc_csub.reserve(m)); HIPCHK(c, c->rlc_cbm.reserve(mb + 8));
-    HIPCHK(c, c->f_ws.reserve(m * 108 * 4)); HIPCHK(c, c->flags.reserve(m)); HIPCHK(c, c->inv_ws.reserve(m * 72 * 4));
+    HIPCHK(c, c->f_ws.reserve(m * 108 * 4)); HIPCHK(c, c->flags.reserve(m));
     HIPCHK(c, hipMemcpyAsync(c->rlc_idx.p, idx.data(), 4 * m, hipMemcpyHostToDevice, c->stream));
     LAUNCH(c, "rlc_gather", k_rlc_gather, m, (const uint32_t*)c->rlc_idx.p, m, d_pks, d_sigs, (const int32_t*)c->h_ws.p, n, (const uint8_t*)c->sub_ok.p,
            (uint8_t*)c->rlc_cpk.p, (uint8_t*)c->rlc_csig.p, (int32_t*)c->rlc_ch.p, (uint8_t*)c->rlc_csub.p);
     LAUNCH(c, "miller_verify", k_miller_verify, m, (const uint8_t*)c->rlc_cpk.p, (const uint8_t*)c->rlc_csig.p, (const int32_t*)c->rlc_ch.p, m,
-           (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p, (int32_t*)c->inv_ws.p);
+           (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
     rc = run_final_exp(c, (int32_t*)c->f_ws.p, m, m, 0, (const uint8_t*)c->flags.p, (const uint8_t*)c->rlc_csub.p, (uint8_t*)c->rlc_cbm.p, nullptr, nullptr);
     if (rc) return rc;
     std::vector<uint8_t> cb(mb);

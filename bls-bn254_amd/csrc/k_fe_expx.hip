@@ -10,5 +10,5 @@ using namespace bn;
 BN_KERNEL k_fe_expx(const int32_t* in, int32_t* out, int32_t* slots, size_t n, size_t stride) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  fp12_store_limbs(out + i, stride, cyclotomic_exp_x_chain(fp12_load_limbs(in + i, stride), slots + i, stride));
+  fp12_store_limbs(out + i, stride, cyclotomic_exp_x_chain(fp12_load_limbs(in + i, stride), Ws{slots, stride, (uint32_t)i * 4u, true}));
 }

@@ -2,8 +2,9 @@
 // Compiled with the tower functions force-inlined (-DBN_FORCE_INLINE) so that the register allocator sees
 // the whole loop body and f / T stay in the 512 VGPR+AGPR of a 1-wave-per-SIMD kernel instead of
 // round-tripping through scratch (r01 profile: 270 KB of scratch traffic per tuple with outlined calls,
-// 41.9 -> 32.5 ms once inlined).  The loop invariants (sig, H, pk) are written once to a limb-major workspace
-// and re-loaded per use instead of occupying 90 registers (-> 31.3 ms).  One kernel per translation unit.
+// 41.9 -> 32.5 ms once inlined).  The loop invariants (sig, H, pk: 72 limbs per lane) are written once to LDS,
+// limb-major (72 KB per 256-lane workgroup), and re-loaded per use instead of occupying 90 registers.
+// One kernel per translation unit.
 #define BN_WANT_LINE_TABLE
 #define BN_LINE_TABLE_QUAL static __device__ const
 #include "lane_ops.h"
@@ -12,12 +13,13 @@ using namespace bn;
 
 static __device__ const int8_t d_ate_naf[bnc::ATE_NAF_LEN] = BN_ATE_NAF_INIT;
 
-BN_KERNEL k_miller_verify(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n, int32_t* f_ws, uint8_t* flags, int32_t* inv_ws) {
+BN_KERNEL k_miller_verify(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n, int32_t* f_ws, uint8_t* flags) {
+  __shared__ int32_t inv_lds[72 * 256];          // each lane touches only its own column: no barrier needed
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   G1A h; h.x = load_fp(h_ws + i, n); h.y = load_fp(h_ws + 9 * n + i, n); h.inf = false;
   uint8_t fl;
-  Fp12 f = lane_miller_verify_ws(pks + 128 * i, sigs + 64 * i, h, d_ate_naf, bnc::ATE_NAF_LEN, BN_NEG_G2_LINE_TABLE, fl, inv_ws + i, n);
+  Fp12 f = lane_miller_verify_ws(pks + 128 * i, sigs + 64 * i, h, d_ate_naf, bnc::ATE_NAF_LEN, BN_NEG_G2_LINE_TABLE, fl, Ws{inv_lds, 256, threadIdx.x * 4u, false});
   fp12_store_limbs(f_ws + i, n, f);
   flags[i] = fl;
 }

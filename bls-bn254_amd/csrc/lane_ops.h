@@ -79,7 +79,7 @@ BN_FUNC Fp12 lane_miller_1(const uint8_t* g1, const uint8_t* g2, const int8_t* n
 // Variant that first writes the validated operands to the limb-major workspace `inv` (72 limbs per tuple) and
 // runs the loop that re-loads them per use (miller_loop_verify_ws).
 BN_FUNC Fp12 lane_miller_verify_ws(const uint8_t* pk_b, const uint8_t* sig_b, const G1A& h, const int8_t* naf, int naf_len,
-                                   const int32_t (*table)[54], uint8_t& flags, int32_t* inv, size_t st) {
+                                   const int32_t (*table)[54], uint8_t& flags, const Ws& inv) {
   bool oks, okp;
   G1A sig = g1_decode(sig_b, oks);
   G2A pk = g2_decode(pk_b, okp);
@@ -87,12 +87,12 @@ BN_FUNC Fp12 lane_miller_verify_ws(const uint8_t* pk_b, const uint8_t* sig_b, co
   bool pk_ok = okp & !pk.inf & g2_on_curve(pk);
   flags = (uint8_t)((sig_ok ? FLAG_SIG_OK : 0) | (pk_ok ? FLAG_PK_OK : 0));
   G1A gp; gp.x = fp_one(); gp.y = fp_norm(fp_add(fp_one(), fp_one())); gp.inf = false;
-  fp_store_mem(inv, st, fp_norm(fp_select(sig_ok, sig.x, gp.x))); fp_store_mem(inv + 9 * st, st, fp_norm(fp_select(sig_ok, sig.y, gp.y)));
-  fp_store_mem(inv + 18 * st, st, fp_norm(h.x)); fp_store_mem(inv + 27 * st, st, fp_norm(h.y));
-  fp2_store_mem(inv + 36 * st, st, fp2_norm(fp2_select(pk_ok, pk.x, fp2_const(bnc::G2_GEN_X))));
-  fp2_store_mem(inv + 54 * st, st, fp2_norm(fp2_select(pk_ok, pk.y, fp2_const(bnc::G2_GEN_Y))));
+  fp_store_mem(inv, fp_norm(fp_select(sig_ok, sig.x, gp.x))); fp_store_mem(ws_at(inv, 9), fp_norm(fp_select(sig_ok, sig.y, gp.y)));
+  fp_store_mem(ws_at(inv, 18), fp_norm(h.x)); fp_store_mem(ws_at(inv, 27), fp_norm(h.y));
+  fp2_store_mem(ws_at(inv, 36), fp2_norm(fp2_select(pk_ok, pk.x, fp2_const(bnc::G2_GEN_X))));
+  fp2_store_mem(ws_at(inv, 54), fp2_norm(fp2_select(pk_ok, pk.y, fp2_const(bnc::G2_GEN_Y))));
   BN_MEM_FENCE;
-  return miller_loop_verify_ws(inv, st, naf, naf_len, table);
+  return miller_loop_verify_ws(inv, naf, naf_len, table);
 }
 BN_FUNC Fp12 lane_miller_verify(const uint8_t* pk_b, const uint8_t* sig_b, const G1A& h, const int8_t* naf, int naf_len,
                                      const int32_t (*table)[54], uint8_t& flags) {

@@ -130,54 +130,48 @@ BN_FUNC Fp12 miller_loop_verify(const G1A& sig, const G1A& h, const G2A& pk, con
 }
 
 // Variant for k_miller_verify: the loop invariants are NOT kept in registers.  They sit in a limb-major
-// workspace `inv` (slots of 9 limbs: 0 sig.x, 1 sig.y, 2 h.x, 3 h.y, 4-5 pk.x, 6-7 pk.y) and are re-loaded
-// where they are used (once per line); BN_OPAQUE hides the pointer from the optimiser in every iteration
-// so the loads are not hoisted back out of the loop.  Frees 90 of the 256 architectural VGPRs for f, T and
-// the temporaries of the current product.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define BN_OPAQUE(p) asm volatile("" : "+v"(p))
-#else
-#define BN_OPAQUE(p) do { } while (0)
-#endif
-BN_FUNC Fp12 miller_loop_verify_ws(const int32_t* inv, size_t st, const int8_t* naf, int naf_len, const int32_t (*table)[54]) {
+// workspace `inv` (slots of 9 limbs: 0 sig.x, 1 sig.y, 2 h.x, 3 h.y, 4-5 pk.x, 6-7 pk.y; LDS in the kernel) and are
+// re-loaded where they are used (once per line); BN_OPAQUE hides the lane offset from the optimiser in every
+// iteration so the loads are not hoisted back out of the loop.  Frees 90 of the 256 architectural VGPRs for f, T
+// and the temporaries of the current product.
+BN_FUNC Fp12 miller_loop_verify_ws(const Ws& inv, const int8_t* naf, int naf_len, const int32_t (*table)[54]) {
   Fp12 f = fp12_one();
-  G2J T = {fp2_load_mem(inv + 36 * st, st), fp2_load_mem(inv + 54 * st, st), fp2_one()};
+  G2J T = {fp2_load_mem(ws_at(inv, 36)), fp2_load_mem(ws_at(inv, 54)), fp2_one()};
   int ti = 0;
+  Ws p = inv;
   for (int j = naf_len - 2; j >= 0; --j) {
-    const int32_t* p = inv;
     f = fp12_sqr(f);
     BN_OPAQUE(p);
-    f = ell(f, line_from_table(table[ti++]), fp_load_mem(p, st), fp_load_mem(p + 9 * st, st));
+    f = ell(f, line_from_table(table[ti++]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)));
     Line l = doubling_step(T);
     BN_OPAQUE(p);
-    f = ell(f, l, fp_load_mem(p + 18 * st, st), fp_load_mem(p + 27 * st, st));
+    f = ell(f, l, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
     int d = naf[j];
     if (d != 0) {
       BN_OPAQUE(p);
-      f = ell(f, line_from_table(table[ti++]), fp_load_mem(p, st), fp_load_mem(p + 9 * st, st));
+      f = ell(f, line_from_table(table[ti++]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)));
       BN_OPAQUE(p);
-      Fp2 qy = fp2_load_mem(p + 54 * st, st);
+      Fp2 qy = fp2_load_mem(ws_at(p, 54));
       Fp2 nqy = fp2_norm(fp2_neg(qy));
-      l = addition_step(T, fp2_load_mem(p + 36 * st, st), fp2_select(d > 0, qy, nqy));
+      l = addition_step(T, fp2_load_mem(ws_at(p, 36)), fp2_select(d > 0, qy, nqy));
       BN_OPAQUE(p);
-      f = ell(f, l, fp_load_mem(p + 18 * st, st), fp_load_mem(p + 27 * st, st));
+      f = ell(f, l, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
     }
   }
-  const int32_t* p = inv;
   BN_OPAQUE(p);
   Fp2 g2 = fp2_const(bnc::GAMMA1[1]), g3 = fp2_const(bnc::GAMMA1[2]);
-  Fp2 q1x = fp2_mul(fp2_norm(fp2_conj(fp2_load_mem(p + 36 * st, st))), g2);
-  Fp2 q1y = fp2_mul(fp2_norm(fp2_conj(fp2_load_mem(p + 54 * st, st))), g3);
+  Fp2 q1x = fp2_mul(fp2_norm(fp2_conj(fp2_load_mem(ws_at(p, 36)))), g2);
+  Fp2 q1y = fp2_mul(fp2_norm(fp2_conj(fp2_load_mem(ws_at(p, 54)))), g3);
   Fp2 q2x = fp2_mul(fp2_norm(fp2_conj(q1x)), g2);
   Fp2 q2y = fp2_norm(fp2_neg(fp2_mul(fp2_norm(fp2_conj(q1y)), g3)));
-  f = ell(f, line_from_table(table[ti++]), fp_load_mem(p, st), fp_load_mem(p + 9 * st, st));
+  f = ell(f, line_from_table(table[ti++]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)));
   Line l = addition_step(T, q1x, q1y);
   BN_OPAQUE(p);
-  f = ell(f, l, fp_load_mem(p + 18 * st, st), fp_load_mem(p + 27 * st, st));
-  f = ell(f, line_from_table(table[ti++]), fp_load_mem(p, st), fp_load_mem(p + 9 * st, st));
+  f = ell(f, l, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
+  f = ell(f, line_from_table(table[ti++]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)));
   l = addition_step(T, q2x, q2y);
   BN_OPAQUE(p);
-  f = ell(f, l, fp_load_mem(p + 18 * st, st), fp_load_mem(p + 27 * st, st));
+  f = ell(f, l, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
   return f;
 }
 
@@ -205,21 +199,20 @@ BN_FUNC Fp12 cyclotomic_exp_x(const Fp12& f) {
 // inlined squaring and one inlined multiply-by-memory-operand in the loop body): the ten named powers
 // live in `slots` (limb-major memory, 10 x 108 limbs per lane) and are read back one Fp6 half at a time.
 struct ExpxOp { int8_t load, sq, mul, store; };
-BN_FUNC Fp12 cyclotomic_exp_x_chain(const Fp12& f, int32_t* slots, size_t st) {
+BN_FUNC Fp12 cyclotomic_exp_x_chain(const Fp12& f, const Ws& slots) {
   const ExpxOp prog[22] = {{-1, 1, -1, 1}, {-1, 1, -1, 2}, {-1, 1, -1, 3}, {-1, 1, 0, 4}, {-1, 0, 1, 5}, {-1, 0, 0, 6}, {3, 0, 4, 7},
                            {5, 0, 6, 8}, {-1, 0, 1, 9}, {4, 1, -1, -1}, {-1, 6, 2, -1}, {-1, 0, 7, -1}, {-1, 7, 7, -1}, {-1, 8, 9, -1},
                            {-1, 0, 1, -1}, {-1, 6, 4, -1}, {-1, 8, 9, -1}, {-1, 6, 9, -1}, {-1, 10, -1, -1}, {-1, 0, 8, -1}, {-1, 6, 9, -1},
                            {-1, 0, 3, -1}};
-  const size_t slot = 108 * st;
-  fp12_store_mem(slots, st, f);
+  fp12_store_mem(slots, f);
   BN_MEM_FENCE;
   Fp12 r = f;
   for (int k = 0; k < 22; ++k) {
     const ExpxOp op = prog[k];
-    if (op.load >= 0) r = fp12_load_mem(slots + op.load * slot, st);
+    if (op.load >= 0) r = fp12_load_mem(ws_at(slots, 108 * op.load));
     for (int q = 0; q < op.sq; ++q) r = fp12_cyclotomic_sqr(r);
-    if (op.mul >= 0) r = fp12_mul_mem(r, slots + op.mul * slot, st);
-    if (op.store >= 0) { fp12_store_mem(slots + op.store * slot, st, r); BN_MEM_FENCE; }
+    if (op.mul >= 0) r = fp12_mul_mem(r, ws_at(slots, 108 * op.mul));
+    if (op.store >= 0) { fp12_store_mem(ws_at(slots, 108 * op.store), r); BN_MEM_FENCE; }
   }
   return r;
 }

@@ -133,14 +133,44 @@ BN_FUNC Fp12 fp12_mul(const Fp12& a, const Fp12& b) {     // fp12.rs:203-210 val
   Fp6 w = fp6_mul(fp6_norm(fp6_sub(a.c0, a.c1)), fp6_norm(fp6_sub(b.c1, b.c0)));   // a0b1 + a1b0 - v0 - v1
   return {fp6_add_mul_v(v0, v1), fp6_norm(fp6_add(fp6_add(w, v0), v1))};
 }
-// ---- operands parked in memory (LDS on the device): limb k of Fp element e at p[(9*e + k) * stride].
-// With stride = workgroup size the 64 lanes of a wave hit 64 consecutive dwords: conflict-free
-// ds_read_b32.  BN_MEM_FENCE stops the compiler from keeping a loaded operand alive in registers across
-// phases (that is the whole point of parking it).
+// ---- operands parked in memory (LDS or an HBM workspace), limb-major.  A Ws names one lane's column of a
+// workspace: limb k of it is base[k * stride + lane].  `base` and `stride` are wave-uniform (scalar registers) and
+// the lane enters as one 32-bit byte offset, so a load is `global_load_dword v, v_lane4, s[row]` (or a
+// ds_read_b32 with an immediate) -- no 64-bit per-lane pointer that would itself be spilled and re-loaded in
+// front of every access.  With stride >= the wave's lane count, the 64 lanes hit 64 consecutive dwords.
+// BN_MEM_FENCE stops the compiler from keeping a loaded operand alive in registers across phases (that is the
+// whole point of parking it); BN_OPAQUE makes the lane offset unknown to the optimiser at that point, so loads
+// through it are neither hoisted out of a loop nor merged with earlier ones.
+// `buf` selects buffer addressing for HBM workspaces on the device: the row base goes into a scalar buffer
+// descriptor and k * stride into the scalar offset, so no per-limb 64-bit address pair is ever formed in (or
+// spilled from) vector registers.  k * stride * 4 must stay below 4 GB (108 limbs x 4 M lanes: 1.8 GB).
+struct Ws { int32_t* base; size_t stride; uint32_t lane4; bool buf; };
+BN_INL Ws ws_at(const Ws& w, size_t limbs) { return {w.base + limbs * w.stride, w.stride, w.lane4, w.buf}; }
+BN_INL int32_t* ws_addr(const Ws& w, int k) { return (int32_t*)((char*)(w.base + (size_t)k * w.stride) + w.lane4); }
+BN_INL int32_t ws_load(const Ws& w, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (w.buf)
+    return __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void*)w.base, 0, -1, 0x00020000), (int)w.lane4,
+                                                (int)(uint32_t)((size_t)k * w.stride * 4), 0);
+#endif
+  return *ws_addr(w, k);
+}
+BN_INL void ws_store(const Ws& w, int k, int32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (w.buf) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, __builtin_amdgcn_make_buffer_rsrc((void*)w.base, 0, -1, 0x00020000), (int)w.lane4,
+                                          (int)(uint32_t)((size_t)k * w.stride * 4), 0);
+    return;
+  }
+#endif
+  *ws_addr(w, k) = v;
+}
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BN_MEM_FENCE asm volatile("" ::: "memory")
+#define BN_OPAQUE(w) asm volatile("" : "+v"((w).lane4))
 #else
 #define BN_MEM_FENCE do { } while (0)
+#define BN_OPAQUE(w) do { } while (0)
 #endif
 #ifdef BN_CHECK
 }  // namespace bn
@@ -150,36 +180,34 @@ namespace bn {
 struct ParkTrk { double lo, hi, tlo, thi, vb; };
 inline std::map<const int32_t*, ParkTrk>& park_trk() { static std::map<const int32_t*, ParkTrk> m; return m; }
 #endif
-BN_INL Fp fp_load_mem(const int32_t* p, size_t stride) {
+BN_INL Fp fp_load_mem(const Ws& w) {
   Fp r;
-  BN_UNROLL for (int k = 0; k < NL; ++k) r.l[k] = p[(size_t)k * stride];
-  BN_TRK(auto it = park_trk().find(p); if (it == park_trk().end()) check_fail("fp_load_mem of an address never stored", 0);
+  BN_UNROLL for (int k = 0; k < NL; ++k) r.l[k] = ws_load(w, k);
+  BN_TRK(auto it = park_trk().find(ws_addr(w, 0)); if (it == park_trk().end()) check_fail("fp_load_mem of an address never stored", 0);
          set_trk(r, it->second.lo, it->second.hi, it->second.tlo, it->second.thi, it->second.vb);)
   return r;
 }
-BN_INL void fp_store_mem(int32_t* p, size_t stride, const Fp& a) {
+BN_INL void fp_store_mem(const Ws& w, const Fp& a) {
   BN_TRK(if (a.lo < -1e-6 || a.hi > 1.0 + 1e-6) check_fail("fp_store_mem needs a normalised value", mag(a));
-         park_trk()[p] = ParkTrk{a.lo, a.hi, a.tlo, a.thi, a.vb};)
-  BN_UNROLL for (int k = 0; k < NL; ++k) p[(size_t)k * stride] = a.l[k];
+         park_trk()[ws_addr(w, 0)] = ParkTrk{a.lo, a.hi, a.tlo, a.thi, a.vb};)
+  BN_UNROLL for (int k = 0; k < NL; ++k) ws_store(w, k, a.l[k]);
 }
-BN_INL Fp2 fp2_load_mem(const int32_t* p, size_t stride) { return {fp_load_mem(p, stride), fp_load_mem(p + 9 * stride, stride)}; }
-BN_INL Fp6 fp6_load_mem(const int32_t* p, size_t stride) {
-  return {fp2_load_mem(p, stride), fp2_load_mem(p + 18 * stride, stride), fp2_load_mem(p + 36 * stride, stride)};
+BN_INL Fp2 fp2_load_mem(const Ws& w) { return {fp_load_mem(w), fp_load_mem(ws_at(w, 9))}; }
+BN_INL Fp6 fp6_load_mem(const Ws& w) { return {fp2_load_mem(w), fp2_load_mem(ws_at(w, 18)), fp2_load_mem(ws_at(w, 36))}; }
+BN_INL void fp2_store_mem(const Ws& w, const Fp2& a) { fp_store_mem(w, a.c0); fp_store_mem(ws_at(w, 9), a.c1); }
+BN_INL void fp6_store_mem(const Ws& w, const Fp6& a) {
+  fp2_store_mem(w, a.c0); fp2_store_mem(ws_at(w, 18), a.c1); fp2_store_mem(ws_at(w, 36), a.c2);
 }
-BN_INL void fp2_store_mem(int32_t* p, size_t stride, const Fp2& a) { fp_store_mem(p, stride, a.c0); fp_store_mem(p + 9 * stride, stride, a.c1); }
-BN_INL void fp6_store_mem(int32_t* p, size_t stride, const Fp6& a) {
-  fp2_store_mem(p, stride, a.c0); fp2_store_mem(p + 18 * stride, stride, a.c1); fp2_store_mem(p + 36 * stride, stride, a.c2);
-}
-BN_INL void fp12_store_mem(int32_t* p, size_t stride, const Fp12& a) { fp6_store_mem(p, stride, a.c0); fp6_store_mem(p + 54 * stride, stride, a.c1); }
-BN_INL Fp12 fp12_load_mem(const int32_t* p, size_t stride) { return {fp6_load_mem(p, stride), fp6_load_mem(p + 54 * stride, stride)}; }
+BN_INL void fp12_store_mem(const Ws& w, const Fp12& a) { fp6_store_mem(w, a.c0); fp6_store_mem(ws_at(w, 54), a.c1); }
+BN_INL Fp12 fp12_load_mem(const Ws& w) { return {fp6_load_mem(w), fp6_load_mem(ws_at(w, 54))}; }
 // a * b with b parked in memory: its Fp6 halves are loaded when needed, never held across phases
-BN_FUNC Fp12 fp12_mul_mem(const Fp12& a, const int32_t* b, size_t stride) {
+BN_FUNC Fp12 fp12_mul_mem(const Fp12& a, const Ws& b) {
   Fp6 v0, v1, w;
-  { Fp6 b0 = fp6_load_mem(b, stride); v0 = fp6_mul(a.c0, b0); }
+  { Fp6 b0 = fp6_load_mem(b); v0 = fp6_mul(a.c0, b0); }
   BN_MEM_FENCE;
-  { Fp6 b1 = fp6_load_mem(b + 54 * stride, stride); v1 = fp6_mul(a.c1, b1); }
+  { Fp6 b1 = fp6_load_mem(ws_at(b, 54)); v1 = fp6_mul(a.c1, b1); }
   BN_MEM_FENCE;
-  { Fp6 b0 = fp6_load_mem(b, stride), b1 = fp6_load_mem(b + 54 * stride, stride);
+  { Fp6 b0 = fp6_load_mem(b), b1 = fp6_load_mem(ws_at(b, 54));
     w = fp6_mul(fp6_norm(fp6_sub(a.c0, a.c1)), fp6_norm(fp6_sub(b1, b0))); }
   return {fp6_add_mul_v(v0, v1), fp6_norm(fp6_add(fp6_add(w, v0), v1))};
 }

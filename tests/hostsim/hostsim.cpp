@@ -59,7 +59,7 @@ int hs_expx_chain_matches(const uint8_t* in) {      // addition chain == binary 
   bool ok;
   Fp12 t = fe_easy(fp12_from_be(in, ok));
   static int32_t slots[108 * 10];
-  Fp12 a = cyclotomic_exp_x(t), c = cyclotomic_exp_x_chain(t, slots, 1);
+  Fp12 a = cyclotomic_exp_x(t), c = cyclotomic_exp_x_chain(t, Ws{slots, 1, 0, false});
   uint8_t ba[384], bc[384];
   fp12_to_be(ba, a); fp12_to_be(bc, c);
   return std::memcmp(ba, bc, 384) == 0;
@@ -114,7 +114,7 @@ void hs_miller_verify_ws(const uint8_t* pk, const uint8_t* sig, const uint8_t* h
   bool ok; G1A h = g1_decode(h64, ok);
   uint8_t flags;
   static int32_t inv[72];
-  Fp12 f = lane_miller_verify_ws(pk, sig, h, bnc::ATE_NAF, bnc::ATE_NAF_LEN, BN_NEG_G2_LINE_TABLE, flags, inv, 1);
+  Fp12 f = lane_miller_verify_ws(pk, sig, h, bnc::ATE_NAF, bnc::ATE_NAF_LEN, BN_NEG_G2_LINE_TABLE, flags, Ws{inv, 1, 0, false});
   fp12_to_be(ml_out, f);
   *flags_out = flags;
 }
