@@ -8,7 +8,9 @@
 using namespace bn;
 
 BN_KERNEL k_fe_expx(const int32_t* in, int32_t* out, int32_t* slots, size_t n, size_t stride) {
+  __shared__ int32_t park_lds[108 * 256];        // each lane touches only its own column: no barrier needed
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  fp12_store_limbs(out + i, stride, cyclotomic_exp_x_chain(fp12_load_limbs(in + i, stride), Ws{slots, stride, (uint32_t)i * 4u, true}));
+  const Ws park = {park_lds, 256, threadIdx.x * 4u, false};
+  fp12_store_limbs(out + i, stride, cyclotomic_exp_x_chain(fp12_load_limbs(in + i, stride), Ws{slots, stride, (uint32_t)i * 4u, true}, &park));
 }

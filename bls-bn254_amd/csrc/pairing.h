@@ -199,7 +199,7 @@ BN_FUNC Fp12 cyclotomic_exp_x(const Fp12& f) {
 // inlined squaring and one inlined multiply-by-memory-operand in the loop body): the ten named powers
 // live in `slots` (limb-major memory, 10 x 108 limbs per lane) and are read back one Fp6 half at a time.
 struct ExpxOp { int8_t load, sq, mul, store; };
-BN_FUNC Fp12 cyclotomic_exp_x_chain(const Fp12& f, const Ws& slots) {
+BN_FUNC Fp12 cyclotomic_exp_x_chain(const Fp12& f, const Ws& slots, const Ws* park = nullptr) {
   const ExpxOp prog[22] = {{-1, 1, -1, 1}, {-1, 1, -1, 2}, {-1, 1, -1, 3}, {-1, 1, 0, 4}, {-1, 0, 1, 5}, {-1, 0, 0, 6}, {3, 0, 4, 7},
                            {5, 0, 6, 8}, {-1, 0, 1, 9}, {4, 1, -1, -1}, {-1, 6, 2, -1}, {-1, 0, 7, -1}, {-1, 7, 7, -1}, {-1, 8, 9, -1},
                            {-1, 0, 1, -1}, {-1, 6, 4, -1}, {-1, 8, 9, -1}, {-1, 6, 9, -1}, {-1, 10, -1, -1}, {-1, 0, 8, -1}, {-1, 6, 9, -1},
@@ -211,7 +211,7 @@ BN_FUNC Fp12 cyclotomic_exp_x_chain(const Fp12& f, const Ws& slots) {
     const ExpxOp op = prog[k];
     if (op.load >= 0) r = fp12_load_mem(ws_at(slots, 108 * op.load));
     for (int q = 0; q < op.sq; ++q) r = fp12_cyclotomic_sqr(r);
-    if (op.mul >= 0) r = fp12_mul_mem(r, ws_at(slots, 108 * op.mul));
+    if (op.mul >= 0) r = fp12_mul_mem(r, ws_at(slots, 108 * op.mul), park);
     if (op.store >= 0) { fp12_store_mem(ws_at(slots, 108 * op.store), r); BN_MEM_FENCE; }
   }
   return r;
@@ -277,6 +277,27 @@ BN_FUNC Fp12 fp12_from_be(const uint8_t* in, bool& ok) {
 BN_INL void fp2_store_limbs(int32_t* out, size_t stride, const Fp2& c) {
   Fp c0 = fp_canon(c.c0), c1 = fp_canon(c.c1);
   BN_UNROLL for (int k = 0; k < NL; ++k) { out[(size_t)k * stride] = c0.l[k]; out[(size_t)(9 + k) * stride] = c1.l[k]; }
+}
+// the same through a workspace reference (buffer addressing on the device)
+BN_INL void fp2_store_limbs(const Ws& w, const Fp2& c) {
+  Fp c0 = fp_canon(c.c0), c1 = fp_canon(c.c1);
+  BN_UNROLL for (int k = 0; k < NL; ++k) { ws_store(w, k, c0.l[k]); ws_store(w, 9 + k, c1.l[k]); }
+}
+BN_FUNC void fp12_store_limbs(const Ws& w, const Fp12& a) {
+  BN_CTX;
+  fp2_store_limbs(w, a.c0.c0); fp2_store_limbs(ws_at(w, 18), a.c0.c1); fp2_store_limbs(ws_at(w, 36), a.c0.c2);
+  fp2_store_limbs(ws_at(w, 54), a.c1.c0); fp2_store_limbs(ws_at(w, 72), a.c1.c1); fp2_store_limbs(ws_at(w, 90), a.c1.c2);
+}
+BN_INL Fp2 fp2_load_limbs(const Ws& w) {
+  Fp2 c;
+  BN_UNROLL for (int k = 0; k < NL; ++k) { c.c0.l[k] = ws_load(w, k); c.c1.l[k] = ws_load(w, 9 + k); }
+  BN_TRK(set_trk(c.c0, 0, 1, 0, 0.006, 1); set_trk(c.c1, 0, 1, 0, 0.006, 1);)
+  return c;
+}
+BN_FUNC Fp12 fp12_load_limbs(const Ws& w) {
+  BN_CTX;
+  return {{fp2_load_limbs(w), fp2_load_limbs(ws_at(w, 18)), fp2_load_limbs(ws_at(w, 36))},
+          {fp2_load_limbs(ws_at(w, 54)), fp2_load_limbs(ws_at(w, 72)), fp2_load_limbs(ws_at(w, 90))}};
 }
 BN_FUNC void fp12_store_limbs(int32_t* out, size_t stride, const Fp12& a) {
   BN_CTX;

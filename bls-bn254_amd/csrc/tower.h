@@ -200,15 +200,29 @@ BN_INL void fp6_store_mem(const Ws& w, const Fp6& a) {
 }
 BN_INL void fp12_store_mem(const Ws& w, const Fp12& a) { fp6_store_mem(w, a.c0); fp6_store_mem(ws_at(w, 54), a.c1); }
 BN_INL Fp12 fp12_load_mem(const Ws& w) { return {fp6_load_mem(w), fp6_load_mem(ws_at(w, 54))}; }
-// a * b with b parked in memory: its Fp6 halves are loaded when needed, never held across phases
-BN_FUNC Fp12 fp12_mul_mem(const Fp12& a, const Ws& b) {
+// a * b with b parked in memory.  Without `park`, b's Fp6 halves are loaded when needed and never held across
+// phases (three loads of b).  With `park` naming an LDS column of 108 limbs, b is read once: b1 - b0 and the first
+// partial product wait in LDS while the others are computed.
+BN_FUNC Fp12 fp12_mul_mem(const Fp12& a, const Ws& b, const Ws* park = nullptr) {
   Fp6 v0, v1, w;
-  { Fp6 b0 = fp6_load_mem(b); v0 = fp6_mul(a.c0, b0); }
-  BN_MEM_FENCE;
-  { Fp6 b1 = fp6_load_mem(ws_at(b, 54)); v1 = fp6_mul(a.c1, b1); }
-  BN_MEM_FENCE;
-  { Fp6 b0 = fp6_load_mem(b), b1 = fp6_load_mem(ws_at(b, 54));
-    w = fp6_mul(fp6_norm(fp6_sub(a.c0, a.c1)), fp6_norm(fp6_sub(b1, b0))); }
+  if (park) {
+    Fp6 b0 = fp6_load_mem(b), b1 = fp6_load_mem(ws_at(b, 54));
+    fp6_store_mem(ws_at(*park, 54), fp6_norm(fp6_sub(b1, b0)));
+    v0 = fp6_mul(a.c0, b0);
+    fp6_store_mem(*park, v0);
+    BN_MEM_FENCE;
+    v1 = fp6_mul(a.c1, b1);
+    BN_MEM_FENCE;
+    w = fp6_mul(fp6_norm(fp6_sub(a.c0, a.c1)), fp6_load_mem(ws_at(*park, 54)));
+    v0 = fp6_load_mem(*park);
+  } else {
+    { Fp6 b0 = fp6_load_mem(b); v0 = fp6_mul(a.c0, b0); }
+    BN_MEM_FENCE;
+    { Fp6 b1 = fp6_load_mem(ws_at(b, 54)); v1 = fp6_mul(a.c1, b1); }
+    BN_MEM_FENCE;
+    { Fp6 b0 = fp6_load_mem(b), b1 = fp6_load_mem(ws_at(b, 54));
+      w = fp6_mul(fp6_norm(fp6_sub(a.c0, a.c1)), fp6_norm(fp6_sub(b1, b0))); }
+  }
   return {fp6_add_mul_v(v0, v1), fp6_norm(fp6_add(fp6_add(w, v0), v1))};
 }
 BN_FUNC Fp12 fp12_sqr(const Fp12& a) {                    // complex squaring, fp12.rs:170-180 value
