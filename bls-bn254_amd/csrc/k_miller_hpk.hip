@@ -10,14 +10,15 @@ using namespace bn;
 static __device__ const int8_t d_ate_naf[bnc::ATE_NAF_LEN] = BN_ATE_NAF_INIT;
 
 BN_KERNEL k_miller_hpk(const int32_t* h_ws, const uint8_t* pks, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* flags) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;      // 32-bit lane index, buffer-addressed workspaces (see k_miller_verify.hip)
   if (i >= n) return;
   bool okp;
-  G2A pk = g2_decode(pks + 128 * i, okp);
+  G2A pk = g2_decode(pks + 128 * (size_t)i, okp);
   bool pk_ok = okp & !pk.inf & g2_on_curve(pk);
   pk.x = fp2_select(pk_ok, pk.x, fp2_const(bnc::G2_GEN_X)); pk.y = fp2_select(pk_ok, pk.y, fp2_const(bnc::G2_GEN_Y));
   pk.inf = false;
-  G1A h; h.x = load_fp(h_ws + i, n); h.y = load_fp(h_ws + 9 * n + i, n); h.inf = false;
-  fp12_store_limbs(f_ws + i, f_stride, miller_loop_1(h, pk, d_ate_naf, bnc::ATE_NAF_LEN));
+  const Ws hw = {const_cast<int32_t*>(h_ws), n, i * 4u, true};
+  G1A h; h.x = fp_load_mem(hw); h.y = fp_load_mem(ws_at(hw, 9)); h.inf = false;
+  fp12_store_limbs(Ws{f_ws, f_stride, i * 4u, true}, miller_loop_1(h, pk, d_ate_naf, bnc::ATE_NAF_LEN));
   flags[i] = pk_ok ? 1 : 0;
 }
