@@ -265,15 +265,22 @@ BN_FUNC void g2_compress(uint8_t* out, const G2A& a) {
 // Straight-line Shallue-van de Woestijne (RFC 9380 F.1), Z = 1, following fp.rs:292-370.  The two
 // is_square tests and the final sqrt of the reference (three Euler/sqrt exponentiations) are each
 // done as ONE a^((p+1)/4) exponentiation whose square is compared with a (fp_sqrt_cand).
-BN_FUNC G1A svdw_g1(const Fp& u_in) {
+// Split in two so that the two maps of hash_to_curve can share one inversion: svdw_g1_den(u) is the value the
+// map inverts, svdw_g1_finish(u, inv0(den)) the rest.
+BN_FUNC Fp svdw_g1_den(const Fp& u_in) {
+  BN_CTX;
+  Fp u2 = fp_sqr(fp_norm(u_in));
+  Fp tv1 = fp_lc2<4, 0>(u2, u2);                                 // c1 = g(Z) = 4
+  return fp_mul(fp_norm(fp_sub(fp_one(), tv1)), fp_norm(fp_add(fp_one(), tv1)));
+}
+BN_FUNC G1A svdw_g1_finish(const Fp& u_in, const Fp& tv3) {       // tv3 = inv0(tv1 * tv2)
   BN_CTX;
   Fp u = fp_norm(u_in);
   Fp c2 = fp_const(bnc::SVDW1_C2), c3 = fp_const(bnc::SVDW1_C3), c4 = fp_const(bnc::SVDW1_C4), one = fp_one(), b = fp_const(bnc::THREE);
   Fp u2 = fp_sqr(u);
-  Fp tv1 = fp_lc2<4, 0>(u2, u2);                                 // c1 = g(Z) = 4
+  Fp tv1 = fp_lc2<4, 0>(u2, u2);
   Fp tv2 = fp_norm(fp_add(one, tv1));
   tv1 = fp_norm(fp_sub(one, tv1));
-  Fp tv3 = fp_inv(fp_mul(tv1, tv2));                             // inv0
   Fp tv4 = fp_mul(fp_mul(fp_mul(u, tv1), tv3), c3);
   Fp x1 = fp_norm(fp_sub(c2, tv4));
   Fp gx1 = fp_norm(fp_add(fp_mul(fp_sqr(x1), x1), b));
@@ -292,10 +299,17 @@ BN_FUNC G1A svdw_g1(const Fp& u_in) {
   r.inf = false;
   return r;
 }
-// hash_to_curve for G1 (g1.rs:910-919): map two field elements, add, no cofactor
+BN_FUNC G1A svdw_g1(const Fp& u) { return svdw_g1_finish(u, fp_inv(svdw_g1_den(u))); }
+// hash_to_curve for G1 (g1.rs:910-919): map two field elements, add, no cofactor.  One inversion serves both
+// maps (1/(d0 d1), then times d1 and d0); a zero denominator keeps the map's inv0(0) = 0.
 BN_FUNC G1A hash_to_g1_from_fields(const Fp& u0, const Fp& u1) {
   BN_CTX;
-  G1A q0 = svdw_g1(u0), q1 = svdw_g1(u1);
+  Fp d0 = svdw_g1_den(u0), d1 = svdw_g1_den(u1);
+  bool z0 = fp_is_zero(d0), z1 = fp_is_zero(d1);
+  Fp e0 = fp_select(z0, fp_one(), d0), e1 = fp_select(z1, fp_one(), d1);
+  Fp inv = fp_inv(fp_mul(e0, e1));
+  Fp i0 = fp_select(z0, fp_zero(), fp_mul(inv, e1)), i1 = fp_select(z1, fp_zero(), fp_mul(inv, e0));
+  G1A q0 = svdw_g1_finish(u0, i0), q1 = svdw_g1_finish(u1, i1);
   return g1_to_affine(proj_add(proj_from_affine(q0), proj_from_affine(q1)));
 }
 

@@ -73,6 +73,10 @@ void hs_hash_to_g1(const uint8_t* msg, size_t len, const uint8_t* dst, uint32_t 
   G1A h = ro ? lane_hash_to_g1(msg, len, dst, dst_len) : lane_encode_to_g1(msg, len, dst, dst_len);
   g1_encode(out, h);
 }
+void hs_g1_from_fields(const uint8_t* u0, const uint8_t* u1, uint8_t* out) {      // the two-map path with its shared inversion
+  bool o0, o1;
+  g1_encode(out, hash_to_g1_from_fields(fp_from_be(u0, o0), fp_from_be(u1, o1)));
+}
 void hs_hash_to_g2(const uint8_t* msg, size_t len, const uint8_t* dst, uint32_t dst_len, int ro, uint8_t* out) {
   g2_encode(out, lane_hash_to_g2(msg, len, dst, dst_len, ro != 0));
 }

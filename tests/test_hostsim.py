@@ -140,3 +140,18 @@ def test_keygen_and_hash_to_scalar(hs, pyref):
     for msg in (b"", b"abc", rnd.randbytes(200)):
         hs.hs_hash_to_scalar(msg, ctypes.c_size_t(len(msg)), dst, len(dst), out)
         assert int.from_bytes(out.raw, "big") == pyref.hash_to_scalar(msg, dst)
+
+
+def test_svdw_shared_inversion_edge_cases(hs, pyref):
+    """hash_to_g1_from_fields shares one inversion between its two SVDW maps; u = +-1/2 makes a map's denominator
+    zero (inv0 path), which the shared inversion must not leak into the other map."""
+    P = pyref.P
+    half = (P + 1) // 2
+    rnd = random.Random(11)
+    out = ctypes.create_string_buffer(64)
+    us = [0, 1, half, P - half, rnd.randrange(P), rnd.randrange(P)]
+    for u0 in us:
+        for u1 in us:
+            hs.hs_g1_from_fields(b32(u0), b32(u1), out)
+            want = pyref.g1_add(pyref.svdw_g1(u0), pyref.svdw_g1(u1))
+            assert out.raw == pyref.g1_to_bytes(want), (u0, u1)
