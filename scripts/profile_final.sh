@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round-end profile set: rocprofv3 kernel stats of the bench command, then three separate PMC passes
+# (SQ counters, FETCH_SIZE, WRITE_SIZE) of one bench step, then the plain bench line.  Run through gpurun.
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$PWD}
+cd /tmp && export TMPDIR=/tmp && cd "$R"
+O=gpurun_out/prof_final
+mkdir -p $O
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1 &&
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_FLAT --kernel-trace --output-format csv -d $O/pmc_sq -o sq -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_sq.log 2>&1 &&
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o fetch -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_fetch.log 2>&1 &&
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o write -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $O/pmc_write.log 2>&1 &&
+timeout -k 10 400 python3 bench.py --steps 5 --warmup 1 > $O/bench.json 2> $O/bench.err
+echo rc=$?
+tail -n 1 $O/bench.json | cut -c1-300

@@ -1,0 +1,38 @@
+"""Copy the round-end profile set from gpurun_out/prof_final into profiles/ and derive profiles/r01_traffic.json
+and the per-kernel VALU-busy / wait fractions quoted in DESIGN.md.  Usage: python scripts/summarize_profiles.py"""
+import collections, csv, json, os, shutil
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof_final")
+DST = os.path.join(ROOT, "profiles")
+os.makedirs(os.path.join(DST, "r01_pmc_final"), exist_ok=True)
+shutil.copy(os.path.join(SRC, "stats", "bench_kernel_stats.csv"), os.path.join(DST, "r01_final_kernel_stats.csv"))
+shutil.copy(os.path.join(SRC, "pmc_sq", "sq_counter_collection.csv"), os.path.join(DST, "r01_pmc_final", "SQ_WAVES_counter_collection.csv"))
+shutil.copy(os.path.join(SRC, "pmc_fetch", "fetch_counter_collection.csv"), os.path.join(DST, "r01_pmc_final", "FETCH_SIZE_counter_collection.csv"))
+shutil.copy(os.path.join(SRC, "pmc_write", "write_counter_collection.csv"), os.path.join(DST, "r01_pmc_final", "WRITE_SIZE_counter_collection.csv"))
+line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
+json.dump(json.loads(line), open(os.path.join(DST, "r01_final_bench.json"), "w"), indent=1)
+
+
+def per_kernel(path):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); launches = collections.defaultdict(set)
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); launches[k].add(r["Dispatch_Id"])
+    return agg, {k: len(v) for k, v in launches.items()}
+
+
+f, fl = per_kernel(os.path.join(SRC, "pmc_fetch", "fetch_counter_collection.csv"))
+w, wl = per_kernel(os.path.join(SRC, "pmc_write", "write_counter_collection.csv"))
+out = {"_source": "profiles/r01_pmc_final/{FETCH,WRITE}_SIZE_counter_collection.csv (rocprofv3 --pmc, separate passes, bench.py --steps 1 "
+                  "--warmup 0, final r01 build); bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch (FETCH_SIZE/WRITE_SIZE in KiB; "
+                  "FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM'); averages over the launches of each kernel in the run", "kernels": {}}
+for k in f:
+    fk, wk = f[k]["FETCH_SIZE"] / fl[k], w[k]["WRITE_SIZE"] / max(wl.get(k, 1), 1)
+    out["kernels"][k] = {"fetch_kib": round(fk), "write_kib": round(wk), "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
+json.dump(out, open(os.path.join(DST, "r01_traffic.json"), "w"), indent=1)
+s, sl = per_kernel(os.path.join(SRC, "pmc_sq", "sq_counter_collection.csv"))
+for k, v in sorted(s.items(), key=lambda kv: -kv[1]["SQ_WAVE_CYCLES"]):
+    wc = v["SQ_WAVE_CYCLES"] or 1
+    print("%-18s launches %2d  VALU-busy %5.1f%%  wait_any %5.1f%%  wait_inst %5.1f%%  cycles/VALU-inst %.2f   HBM %.2f GB/launch" % (
+        k, sl[k], 100 * v["SQ_ACTIVE_INST_VALU"] / wc, 100 * v["SQ_WAIT_ANY"] / wc, 100 * v["SQ_WAIT_INST_ANY"] / wc,
+        wc / max(v["SQ_INSTS_VALU"], 1) , out["kernels"].get(k, {}).get("hbm_bytes_per_launch", 0) / 1e9))
