@@ -59,10 +59,14 @@ int hs_expx_chain_matches(const uint8_t* in) {      // addition chain == binary 
   bool ok;
   Fp12 t = fe_easy(fp12_from_be(in, ok));
   static int32_t slots[108 * 10];
-  Fp12 a = cyclotomic_exp_x(t), c = cyclotomic_exp_x_chain(t, Ws{slots, 1, 0, false});
+  static int32_t park[108];
+  const Ws pk = {park, 1, 0, false};                 // the kernel's path: partial products parked (LDS on the device)
+  Fp12 a = cyclotomic_exp_x(t), c = cyclotomic_exp_x_chain(t, Ws{slots, 1, 0, false}, &pk);
+  Fp12 c2 = cyclotomic_exp_x_chain(t, Ws{slots, 1, 0, false});
+  uint8_t bc2[384]; fp12_to_be(bc2, c2);
   uint8_t ba[384], bc[384];
   fp12_to_be(ba, a); fp12_to_be(bc, c);
-  return std::memcmp(ba, bc, 384) == 0;
+  return std::memcmp(ba, bc, 384) == 0 && std::memcmp(ba, bc2, 384) == 0;
 }
 void hs_fp12_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
   bool o1, o2;
