@@ -204,9 +204,20 @@ BN_INL Fp fp_lc3(const Fp& x1, const Fp& x2, const Fp& x3) {
     if (lc_abs(K1) == 1) BN_HIDE_RANGE(a1);
     if (lc_abs(K2) == 1) BN_HIDE_RANGE(a2);
     if (lc_abs(K3) == 1) BN_HIDE_RANGE(a3);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BN_LC_MAD)
+    // Small constants hidden in scalar registers: every term becomes one v_mad_i64_i32.  Left visible, the compiler
+    // strength-reduces x * -2 or x * 1 into sign extension + 64-bit shift + subtract with borrow (5 instructions).
+    int32_t k1 = K1, k2 = K2, k3 = K3;
+    asm("" : "+s"(k1)); asm("" : "+s"(k2)); asm("" : "+s"(k3));
+    int64_t t = REDUCE ? -(int64_t)q * bnc::P[i] : 0;
+    if (K3 != 0) t += (int64_t)a3 * k3;
+    t += (int64_t)a2 * k2;
+    t += (int64_t)a1 * k1;
+#else
     int64_t t = (int64_t)a1 * K1 + (int64_t)a2 * K2;
     if (K3 != 0) t += (int64_t)a3 * K3;
     if (REDUCE) t -= (int64_t)q * bnc::P[i];
+#endif
     lo[i] = (int32_t)((uint32_t)t & (uint32_t)MASK);
     c[i] = (int32_t)(t >> RB);
   }
