@@ -190,9 +190,19 @@ BN_INL Fp fp_lc3(const Fp& x1, const Fp& x2, const Fp& x3) {
   Fp r;
   int32_t lo[NL], c[NL];
   int32_t q = 0;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BN_LC_MAD)
+  // Small constants hidden in scalar registers: every term becomes one v_mad_i64_i32.  Left visible, the compiler
+  // strength-reduces x * -2 or x * 1 into sign extension + 64-bit shift + subtract with borrow (5 instructions),
+  // and zero-extends known-non-negative limbs with whatever register "is known to hold 0" (a spilled one, in the
+  // Miller kernel: hundreds of scratch re-loads per iteration).
+  int32_t k1 = K1, k2 = K2, k3 = K3;
+  asm("; lc k1" : "+s"(k1)); asm("; lc k2" : "+s"(k2)); asm("; lc k3" : "+s"(k3));   // distinct texts: equal constants must not be merged, or x1*k + x2*k is refactored into a 64-bit (x1 + x2) * k
+#else
+  const int32_t k1 = K1, k2 = K2, k3 = K3;
+#endif
   if (REDUCE) {
-    int64_t te = (int64_t)x1.l[NL - 1] * K1 + (int64_t)x2.l[NL - 1] * K2;
-    if (K3 != 0) te += (int64_t)x3.l[NL - 1] * K3;
+    int64_t te = (int64_t)x1.l[NL - 1] * k1 + (int64_t)x2.l[NL - 1] * k2;
+    if (K3 != 0) te += (int64_t)x3.l[NL - 1] * k3;
     q = (int32_t)((te * bnc::LC_QINV) >> 52);
   }
   BN_UNROLL for (int i = 0; i < NL; ++i) {
@@ -205,10 +215,6 @@ BN_INL Fp fp_lc3(const Fp& x1, const Fp& x2, const Fp& x3) {
     if (lc_abs(K2) == 1) BN_HIDE_RANGE(a2);
     if (lc_abs(K3) == 1) BN_HIDE_RANGE(a3);
 #if defined(__HIP_DEVICE_COMPILE__) && defined(BN_LC_MAD)
-    // Small constants hidden in scalar registers: every term becomes one v_mad_i64_i32.  Left visible, the compiler
-    // strength-reduces x * -2 or x * 1 into sign extension + 64-bit shift + subtract with borrow (5 instructions).
-    int32_t k1 = K1, k2 = K2, k3 = K3;
-    asm("" : "+s"(k1)); asm("" : "+s"(k2)); asm("" : "+s"(k3));
     int64_t t = REDUCE ? -(int64_t)q * bnc::P[i] : 0;
     if (K3 != 0) t += (int64_t)a3 * k3;
     t += (int64_t)a2 * k2;

@@ -74,6 +74,11 @@ BN_FUNC Fp12 ell(const Fp12& f, const Line& l, const Fp& px, const Fp& py) {
   BN_CTX;
   return fp12_mul_by_034(f, fp2_mul_fp(l.c0, py), fp2_mul_fp(l.c1, px), l.c2);
 }
+// f * la(Pa) * lb(Pb): both lines scaled by their G1 points, multiplied together first (fp12_mul_by_two_lines)
+BN_FUNC Fp12 ell2(const Fp12& f, const Line& la, const Fp& pax, const Fp& pay, const Line& lb, const Fp& pbx, const Fp& pby) {
+  BN_CTX;
+  return fp12_mul_by_two_lines(f, fp2_mul_fp(la.c0, pay), fp2_mul_fp(la.c1, pax), la.c2, fp2_mul_fp(lb.c0, pby), fp2_mul_fp(lb.c1, pbx), lb.c2);
+}
 BN_INL Line line_from_table(const int32_t* t) {                  // 54 strict limbs from the generated table
   return {fp2_from_limbs(t), fp2_from_limbs(t + 18), fp2_from_limbs(t + 36)};
 }
@@ -139,23 +144,21 @@ BN_FUNC Fp12 miller_loop_verify_ws(const Ws& inv, const int8_t* naf, int naf_len
   G2J T = {fp2_load_mem(ws_at(inv, 36)), fp2_load_mem(ws_at(inv, 54)), fp2_one()};
   int ti = 0;
   Ws p = inv;
+  // per step: the variable line first (T is the register-hungry part), then both lines are scaled and folded into f
+  // as one product (ell2): 23 Fp2 products instead of 26
   for (int j = naf_len - 2; j >= 0; --j) {
     f = fp12_sqr(f);
-    BN_OPAQUE(p);
-    f = ell(f, line_from_table(table[ti++]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)));
     Line l = doubling_step(T);
     BN_OPAQUE(p);
-    f = ell(f, l, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
+    f = ell2(f, line_from_table(table[ti++]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)), l, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
     int d = naf[j];
     if (d != 0) {
-      BN_OPAQUE(p);
-      f = ell(f, line_from_table(table[ti++]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)));
       BN_OPAQUE(p);
       Fp2 qy = fp2_load_mem(ws_at(p, 54));
       Fp2 nqy = fp2_norm(fp2_neg(qy));
       l = addition_step(T, fp2_load_mem(ws_at(p, 36)), fp2_select(d > 0, qy, nqy));
       BN_OPAQUE(p);
-      f = ell(f, l, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
+      f = ell2(f, line_from_table(table[ti++]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)), l, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
     }
   }
   BN_OPAQUE(p);
@@ -164,14 +167,12 @@ BN_FUNC Fp12 miller_loop_verify_ws(const Ws& inv, const int8_t* naf, int naf_len
   Fp2 q1y = fp2_mul(fp2_norm(fp2_conj(fp2_load_mem(ws_at(p, 54)))), g3);
   Fp2 q2x = fp2_mul(fp2_norm(fp2_conj(q1x)), g2);
   Fp2 q2y = fp2_norm(fp2_neg(fp2_mul(fp2_norm(fp2_conj(q1y)), g3)));
-  f = ell(f, line_from_table(table[ti++]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)));
   Line l = addition_step(T, q1x, q1y);
   BN_OPAQUE(p);
-  f = ell(f, l, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
-  f = ell(f, line_from_table(table[ti++]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)));
+  f = ell2(f, line_from_table(table[ti++]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)), l, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
   l = addition_step(T, q2x, q2y);
   BN_OPAQUE(p);
-  f = ell(f, l, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
+  f = ell2(f, line_from_table(table[ti++]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)), l, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
   return f;
 }
 

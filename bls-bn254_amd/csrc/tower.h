@@ -252,6 +252,23 @@ BN_FUNC Fp12 fp12_mul_by_034(const Fp12& f, const Fp2& o0, const Fp2& o3, const 
   Fp6 e = fp6_mul_by_01(fp6_norm(fp6_add(f.c0, f.c1)), fp2_norm(fp2_add(o0, o3)), o4);
   return {fp6_add_mul_v(a, b), fp6_norm(fp6_sub(fp6_sub(e, a), b))};
 }
+// f * la * lb for two sparse lines la = a0 + a3 w + a4 v w, lb likewise: first the product of the lines
+//   (a0 b0 + xi a4 b4) + a3 b3 v + (a3 b4 + a4 b3) v^2 + (a0 b3 + a3 b0) w + (a0 b4 + a4 b0) v w      (6 Fp2 products),
+// then one Fp12 product that uses the missing v^2 w coefficient (17 Fp2 products): 23 instead of 2 x 13.
+BN_FUNC Fp12 fp12_mul_by_two_lines(const Fp12& f, const Fp2& a0, const Fp2& a3, const Fp2& a4, const Fp2& b0, const Fp2& b3, const Fp2& b4) {
+  BN_CTX;
+  Fp2 m00 = fp2_mul(a0, b0), m33 = fp2_mul(a3, b3), m44 = fp2_mul(a4, b4);
+  Fp2 w34 = fp2_mul(fp2_sub(a3, a4), fp2_sub(b3, b4));
+  Fp2 w03 = fp2_mul(fp2_sub(a0, a3), fp2_sub(b0, b3));
+  Fp2 w04 = fp2_mul(fp2_sub(a0, a4), fp2_sub(b0, b4));
+  Fp6 l0 = {fp2_add_mul_xi(m00, m44), m33, fp2_norm(fp2_sub(fp2_add(m33, m44), w34))};
+  Fp2 l10 = fp2_norm(fp2_sub(fp2_add(m00, m33), w03)), l11 = fp2_norm(fp2_sub(fp2_add(m00, m44), w04));
+  Fp6 v0 = fp6_mul(f.c0, l0);
+  Fp6 v1 = fp6_mul_by_01(f.c1, l10, l11);
+  Fp6 dl = {fp2_norm(fp2_sub(l10, l0.c0)), fp2_norm(fp2_sub(l11, l0.c1)), fp2_norm(fp2_neg(l0.c2))};       // l1 - l0
+  Fp6 w = fp6_mul(fp6_norm(fp6_sub(f.c0, f.c1)), dl);
+  return {fp6_add_mul_v(v0, v1), fp6_norm(fp6_add(fp6_add(w, v0), v1))};
+}
 // Frobenius^k, k = 1..3: coefficient of w^i -> conj^k(.) * xi^(i (p^k-1)/6)   (E3 fixed)
 template <int K, int I>
 BN_INL Fp2 fp12_frob_coeff(const Fp2& in) {                     // coefficient of w^I
