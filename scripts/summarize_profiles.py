@@ -30,6 +30,13 @@ for k in f:
     fk, wk = f[k]["FETCH_SIZE"] / fl[k], w[k]["WRITE_SIZE"] / max(wl.get(k, 1), 1)
     out["kernels"][k] = {"fetch_kib": round(fk), "write_kib": round(wk), "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
 json.dump(out, open(os.path.join(DST, "r01_traffic.json"), "w"), indent=1)
+# the bench line above was produced before this traffic file existed: carry the PMC figure of the same build into it
+bj = json.load(open(os.path.join(DST, "r01_final_bench.json")))
+t = out["kernels"]["k_miller_verify"]["hbm_bytes_per_launch"]
+bj["roofline"]["traffic"] = t
+bj["roofline"]["traffic_note"] = ("PMC FETCH_SIZE/WRITE_SIZE of the same kernel at the same batch size (profiles/r01_traffic.json): %.1f KB per tuple "
+                                  "against ~1.4 KB algorithmic (inputs 0.3 KB, H 72 B, f out 432 B, line table from cache)" % (t / 262144 / 1024.0))
+json.dump(bj, open(os.path.join(DST, "r01_final_bench.json"), "w"), indent=1)
 s, sl = per_kernel(os.path.join(SRC, "pmc_sq", "sq_counter_collection.csv"))
 for k, v in sorted(s.items(), key=lambda kv: -kv[1]["SQ_WAVE_CYCLES"]):
     wc = v["SQ_WAVE_CYCLES"] or 1
