@@ -213,7 +213,7 @@ static int run_final_exp(blsbn254_ctx* c, int32_t* f, size_t n, size_t stride, i
   LAUNCH(c, "fe_expx", k_fe_expx, n, (const int32_t*)B, X, S, n, stride);
   LAUNCH(c, "fe_h2", k_fe_h2, n, (const int32_t*)X, (const int32_t*)B, C, B2, D, n, stride);
   LAUNCH(c, "fe_expx", k_fe_expx, n, (const int32_t*)D, X, S, n, stride);
-  LAUNCH(c, "fe_h3", k_fe_h3, n, (const int32_t*)f, (const int32_t*)A, (const int32_t*)C, (const int32_t*)B2, (const int32_t*)X, n, stride,
+  LAUNCH(c, "fe_h3", k_fe_h3, n, (const int32_t*)f, (const int32_t*)A, (const int32_t*)C, (const int32_t*)B2, (const int32_t*)X, S, n, stride,
          flags, sub_ok, d_bitmap, d_gt, d_is_one, mode);
   return 0;
 }

@@ -318,4 +318,29 @@ BN_FUNC Fp12 fp12_load_limbs(const int32_t* in, size_t stride) {
           {fp2_load_limbs(in + 54 * stride, stride), fp2_load_limbs(in + 72 * stride, stride), fp2_load_limbs(in + 90 * stride, stride)}};
 }
 
+// fe_h3 as a small uniform interpreter for the phase kernel (k_fe_h3.hip): ONE inlined multiply-by-memory-operand
+// in the loop body instead of eight inlined products, the running value r in registers, every other factor read from a
+// limb-major workspace by fp12_mul_mem.  src[0..4] = t, a, c, b2, x0 (canonical limbs, as the phase kernels store
+// them); tmp = 4 x 108 limbs for e, e^(p^2), d^p, l3^(p^3).  Same value as fe_h3:
+//   e = b2 x0, d = a e, l3 = conj(t) d = conj(t conj(d)), result = (c e t) d^p e^(p^2) l3^(p^3).
+struct H3Op { int8_t pre, mul, post; };      // pre: 1 r = b2, 2 r = conj(r), 3 r = e;  mul: operand index (5.. = tmp slots);  post: see below
+BN_FUNC Fp12 fe_h3_loop(const Ws* src, const Ws& tmp, const Ws* park) {
+  const H3Op prog[8] = {{1, 4, 1}, {0, 1, 2}, {2, 0, 3}, {3, 2, 0}, {0, 0, 0}, {0, 7, 0}, {0, 6, 0}, {0, 8, 0}};
+  Fp12 r = fp12_one();
+  for (int k = 0; k < 8; ++k) {
+    const H3Op op = prog[k];
+    if (op.pre == 1) r = fp12_load_mem(src[3]);
+    else if (op.pre == 2) r = fp12_conj(r);
+    else if (op.pre == 3) r = fp12_load_mem(tmp);
+    const int m = op.mul;
+    const Ws b = m == 0 ? src[0] : m == 1 ? src[1] : m == 2 ? src[2] : m == 4 ? src[4] : ws_at(tmp, 108 * (size_t)(m - 5));
+    r = fp12_mul_mem(r, b, park);
+    if (op.post == 1) { fp12_store_mem(tmp, r); fp12_store_mem(ws_at(tmp, 108), fp12_frob<2>(r)); }      // e, e^(p^2)
+    else if (op.post == 2) fp12_store_mem(ws_at(tmp, 216), fp12_frob<1>(r));                              // d^p
+    else if (op.post == 3) fp12_store_mem(ws_at(tmp, 324), fp12_frob<3>(fp12_conj(r)));                   // l3^(p^3)
+    BN_MEM_FENCE;
+  }
+  return r;
+}
+
 }  // namespace bn

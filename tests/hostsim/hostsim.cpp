@@ -68,6 +68,26 @@ int hs_expx_chain_matches(const uint8_t* in) {      // addition chain == binary 
   fp12_to_be(ba, a); fp12_to_be(bc, c);
   return std::memcmp(ba, bc, 384) == 0 && std::memcmp(ba, bc2, 384) == 0;
 }
+int hs_fe_h3_loop_matches(const uint8_t* in) {      // interpreter form of h3 (the kernel's) == register form, on a full final exponentiation
+  bool ok;
+  Fp12 t = fe_easy(fp12_from_be(in, ok)), a, b, c, b2, d2;
+  fe_h1(cyclotomic_exp_x(t), a, b);
+  fe_h2(cyclotomic_exp_x(b), b, c, b2, d2);
+  Fp12 x0 = cyclotomic_exp_x(d2);
+  static int32_t ws[108 * 5], tmp[108 * 4], park[108];
+  const Fp12* vals[5] = {&t, &a, &c, &b2, &x0};
+  Ws w[5];
+  for (int k = 0; k < 5; ++k) {                      // canonical limbs, as fp12_store_limbs leaves them in the phase buffers
+    w[k] = Ws{ws + 108 * k, 1, 0, false};
+    fp12_store_limbs(ws + 108 * k, 1, *vals[k]);
+    fp12_store_mem(w[k], fp12_load_limbs(ws + 108 * k, 1));
+  }
+  const Ws pk = {park, 1, 0, false};
+  Fp12 r1 = fe_h3(t, a, c, b2, x0), r2 = fe_h3_loop(w, Ws{tmp, 1, 0, false}, &pk);
+  uint8_t b1[384], bb[384];
+  fp12_to_be(b1, r1); fp12_to_be(bb, r2);
+  return std::memcmp(b1, bb, 384) == 0;
+}
 void hs_fp12_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
   bool o1, o2;
   Fp12 x = fp12_from_be(a, o1), y = fp12_from_be(b, o2);
