@@ -148,17 +148,22 @@ BN_FUNC Fp12 miller_loop_verify_ws(const Ws& inv, const int8_t* naf, int naf_len
   // as one product (ell2): 23 Fp2 products instead of 26
   for (int j = naf_len - 2; j >= 0; --j) {
     f = fp12_sqr(f);
-    Line l = doubling_step(T);
     BN_OPAQUE(p);
-    f = ell2(f, line_from_table(table[ti++]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)), l, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
+    Fp sx = fp_load_mem(p), sy = fp_load_mem(ws_at(p, 9)), hx = fp_load_mem(ws_at(p, 18)), hy = fp_load_mem(ws_at(p, 27));
+    BN_SCHED_BARRIER;                 // the four LDS reads are issued here; the doubling step hides their latency
+    Line l = doubling_step(T);
+    f = ell2(f, line_from_table(table[ti++]), sx, sy, l, hx, hy);
     int d = naf[j];
     if (d != 0) {
       BN_OPAQUE(p);
       Fp2 qy = fp2_load_mem(ws_at(p, 54));
       Fp2 nqy = fp2_norm(fp2_neg(qy));
-      l = addition_step(T, fp2_load_mem(ws_at(p, 36)), fp2_select(d > 0, qy, nqy));
+      Fp2 qx = fp2_load_mem(ws_at(p, 36));
       BN_OPAQUE(p);
-      f = ell2(f, line_from_table(table[ti++]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)), l, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
+      sx = fp_load_mem(p); sy = fp_load_mem(ws_at(p, 9)); hx = fp_load_mem(ws_at(p, 18)); hy = fp_load_mem(ws_at(p, 27));
+      BN_SCHED_BARRIER;
+      l = addition_step(T, qx, fp2_select(d > 0, qy, nqy));
+      f = ell2(f, line_from_table(table[ti++]), sx, sy, l, hx, hy);
     }
   }
   BN_OPAQUE(p);
