@@ -262,9 +262,9 @@ BN_FUNC void g2_compress(uint8_t* out, const G2A& a) {
 }
 
 // ------------------------------------------------------------------ SVDW maps
-// Straight-line Shallue-van de Woestijne (RFC 9380 F.1), Z = 1, following fp.rs:292-370.  The two
-// is_square tests and the final sqrt of the reference (three Euler/sqrt exponentiations) are each
-// done as ONE a^((p+1)/4) exponentiation whose square is compared with a (fp_sqrt_cand).
+// Straight-line Shallue-van de Woestijne (RFC 9380 F.1), Z = 1, following fp.rs:292-370.  Of the reference's
+// four exponentiations per map (inv0, two Euler tests, one square root) two remain: the Euler tests are Jacobi
+// symbols (fp_is_square) and the inversion is shared between the two maps of hash_to_curve.
 // Split in two so that the two maps of hash_to_curve can share one inversion: svdw_g1_den(u) is the value the
 // map inverts, svdw_g1_finish(u, inv0(den)) the rest.
 BN_FUNC Fp svdw_g1_den(const Fp& u_in) {
@@ -289,11 +289,12 @@ BN_FUNC G1A svdw_g1_finish(const Fp& u_in, const Fp& tv3) {       // tv3 = inv0(
   Fp x3 = fp_mul(fp_sqr(tv2), tv3);
   x3 = fp_norm(fp_add(fp_mul(fp_sqr(x3), c4), one));
   Fp gx3 = fp_norm(fp_add(fp_mul(fp_sqr(x3), x3), b));
-  bool e1, e2, e3;
-  Fp y1 = fp_sqrt_cand(gx1, e1), y2 = fp_sqrt_cand(gx2, e2), y3 = fp_sqrt_cand(gx3, e3);
+  // the two is_square tests by Jacobi symbol (no exponentiation), then ONE square root of the selected g(x):
+  // g(x3) is a square whenever g(x1) and g(x2) are not (the product of the three is one)
+  bool e1 = fp_is_square(gx1), e2 = fp_is_square(gx2), sq;
   G1A r;
   r.x = fp_select(e1, x1, fp_select(e2, x2, x3));
-  Fp y = fp_select(e1, y1, fp_select(e2, y2, y3));
+  Fp y = fp_sqrt_cand(fp_select(e1, gx1, fp_select(e2, gx2, gx3)), sq);
   bool flip = fp_sgn0(u) != fp_sgn0(y);
   r.y = fp_select(flip, fp_norm(fp_neg(y)), y);
   r.inf = false;

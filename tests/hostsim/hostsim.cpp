@@ -27,6 +27,7 @@ void hs_fp_mix(const uint8_t* a, const uint8_t* b, uint8_t* out) {
   Fp t = fp_mul(fp_add(x, y), fp_sub(x, y));
   fp_to_be(out, fp_lc3<1, 9, -1>(t, x, y));
 }
+int hs_fp_is_square(const uint8_t* a) { bool o; return fp_is_square(fp_from_be(a, o)) ? 1 : 0; }
 int hs_fp_decode_ok(const uint8_t* a) { bool o; (void)fp_from_be(a, o); return o; }
 void hs_fp_from_okm(const uint8_t* okm, uint8_t* out) { fp_to_be(out, fp_from_okm(okm)); }
 void hs_fr_from_okm(const uint8_t* okm, uint8_t* out) { fr_to_be(out, fr_from_okm(okm)); }

@@ -156,3 +156,13 @@ def test_svdw_shared_inversion_edge_cases(hs, pyref):
             hs.hs_g1_from_fields(b32(u0), b32(u1), out)
             want = pyref.g1_add(pyref.svdw_g1(u0), pyref.svdw_g1(u1))
             assert out.raw == pyref.g1_to_bytes(want), (u0, u1)
+
+
+def test_is_square_by_jacobi_symbol(hs, pyref):
+    """fp_is_square (binary Jacobi algorithm, no exponentiation) == Euler's criterion, zero counted as a square."""
+    P = pyref.P
+    rnd = random.Random(12)
+    vals = [0, 1, 2, 3, 4, P - 1, P - 2, (P + 1) // 2, 2**253, 2**253 + 1] + [rnd.randrange(P) for _ in range(300)]
+    vals += [v * v % P for v in vals[:40]]
+    for v in vals:
+        assert hs.hs_fp_is_square(b32(v)) == (1 if pow(v, (P - 1) // 2, P) in (0, 1) else 0), v
