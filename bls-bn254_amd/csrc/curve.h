@@ -327,9 +327,7 @@ BN_FUNC Fp2 fp2_pow(const Fp2& a, Exp256 e) {
 }
 BN_FUNC bool fp2_is_square(const Fp2& a) {                  // fp2.rs:441-452: norm is a square in Fp
   Fp2 n = fp2_norm(a);
-  bool e;
-  (void)fp_sqrt_cand(fp_dot2(n.c0, n.c0, n.c1, n.c1), e);
-  return e;
+  return fp_is_square(fp_dot2(n.c0, n.c0, n.c1, n.c1));       // Jacobi symbol, no exponentiation
 }
 // Algorithm 9 of eprint 2012/685 (fp2.rs:172-218); returns a root when a is a square
 BN_FUNC Fp2 fp2_sqrt(const Fp2& a_in) {
