@@ -43,14 +43,8 @@
 // nothing is scheduled across this point (device only): used to keep a prefetch above the work that hides it
 #if defined(__HIP_DEVICE_COMPILE__)
 #define BN_SCHED_BARRIER __builtin_amdgcn_sched_barrier(0)
-#ifdef BN_LC_HIDE_RANGE
-#define BN_HIDE_RANGE(x) asm("" : "+v"(x))
-#else
-#define BN_HIDE_RANGE(x) ((void)0)
-#endif
 #else
 #define BN_SCHED_BARRIER ((void)0)
-#define BN_HIDE_RANGE(x) ((void)0)
 #endif
 
 #ifdef BN_CHECK
@@ -206,14 +200,7 @@ BN_INL Fp fp_lc3(const Fp& x1, const Fp& x2, const Fp& x3) {
     q = (int32_t)((te * bnc::LC_QINV) >> 52);
   }
   BN_UNROLL for (int i = 0; i < NL; ++i) {
-    // A limb that enters with coefficient +-1 is widened to 64 bits.  When the compiler can prove it non-negative
-    // it zero-extends with "some register known to hold 0" -- in the Miller kernel the high half of a spilled 64-bit
-    // pair, re-loaded from scratch at every use.  -DBN_LC_HIDE_RANGE hides the value's range and so forces a
-    // one-instruction sign extension instead (opt-in per translation unit: elsewhere the zero is free).
-    int32_t a1 = x1.l[i], a2 = x2.l[i], a3 = x3.l[i];
-    if (lc_abs(K1) == 1) BN_HIDE_RANGE(a1);
-    if (lc_abs(K2) == 1) BN_HIDE_RANGE(a2);
-    if (lc_abs(K3) == 1) BN_HIDE_RANGE(a3);
+    const int32_t a1 = x1.l[i], a2 = x2.l[i], a3 = x3.l[i];
 #if defined(__HIP_DEVICE_COMPILE__) && defined(BN_LC_MAD)
     int64_t t = REDUCE ? -(int64_t)q * bnc::P[i] : 0;
     if (K3 != 0) t += (int64_t)a3 * k3;
