@@ -2,6 +2,7 @@
 // There is no CPU fallback in this file: every entry point launches kernels or fails.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -36,7 +37,9 @@ struct blsbn254_ctx {
   DevBuf in_a, in_b, in_c, in_off, dst, h_ws, f_ws, f_ws2, flags, sub_ok, status, bitmap, out, scalars, misc;
   DevBuf fe[6];          // final-exponentiation phase buffers (x, a, b, c, b2, d), 108 x n limbs each
   DevBuf rlc_a2, rlc_a, rlc_b, rlc_elig, rlc_f2, rlc_bytes, rlc_neg, rlc_ok, rlc_idx, rlc_cpk, rlc_csig, rlc_ch, rlc_csub, rlc_cbm;   // RLC batch verification
+  DevBuf status_all;     // per-element decode status of a chunked call, all chunks
   DevBuf fe_slots;       // the ten named powers of the t -> t^x addition chain, 10 x 108 x n limbs
+  size_t chunk = (size_t)1 << 22;   // tuples per launch of the chunked entry points (BLSBN254_CHUNK_LANES overrides: tests)
   bool profiling = false;
   std::map<std::string, ProfEntry> prof;
   std::string last_error;
@@ -95,6 +98,10 @@ int blsbn254_ctx_create(int device, blsbn254_ctx** out) {
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return BLSBN254_E_NO_DEVICE;
   blsbn254_ctx* c = new blsbn254_ctx();
   c->device = device;
+  if (const char* e = std::getenv("BLSBN254_CHUNK_LANES")) {
+    size_t v = (size_t)std::strtoull(e, nullptr, 10) & ~(size_t)7;        // multiples of 8: bitmap bytes must not straddle chunks
+    if (v >= 8 && v <= ((size_t)1 << 23)) c->chunk = v;
+  }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return BLSBN254_E_HIP; }
   *out = c;
   return 0;
@@ -104,7 +111,7 @@ void blsbn254_ctx_destroy(blsbn254_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto& kv : c->prof) for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
-  DevBuf* bufs[] = {&c->in_a, &c->in_b, &c->in_c, &c->in_off, &c->dst, &c->h_ws, &c->f_ws, &c->f_ws2, &c->flags, &c->sub_ok, &c->status, &c->bitmap, &c->out, &c->scalars, &c->misc};
+  DevBuf* bufs[] = {&c->in_a, &c->in_b, &c->in_c, &c->in_off, &c->dst, &c->h_ws, &c->f_ws, &c->f_ws2, &c->flags, &c->sub_ok, &c->status, &c->status_all, &c->bitmap, &c->out, &c->scalars, &c->misc};
   for (DevBuf* b : bufs) b->release();
   for (DevBuf& b : c->fe) b.release();
   c->fe_slots.release();
@@ -198,10 +205,17 @@ static int read_status(blsbn254_ctx* c, const uint8_t* d_status, int idx, uint8_
   return 0;
 }
 
+// The kernels address limb-major workspaces through a buffer descriptor with a 32-bit scalar byte offset
+// (limb index x stride x 4, tower.h `Ws`): a launch may span at most MAX_LANES tuples (107 x 8 Mi x 4 B < 4 GiB).
+// Independent-element entry points are processed in chunks of ctx->chunk (4 Mi); the product-type ones reject more.
+static const size_t MAX_LANES = (size_t)1 << 23;
+#define CHECK_LANES(c, n) do { if ((n) > MAX_LANES) { (c)->last_error = "more than 2^23 elements in one product-type call"; return BLSBN254_E_ARG; } } while (0)
+
 // Final exponentiation of the n Fp12 values at f (limb-major, `stride`), in place for the easy part.
 //   mode 0: verify bitmap (flags / sub_ok / d_bitmap)   mode 1: Gt bytes   mode 3: single is_one flag (n == 1)
 static int run_final_exp(blsbn254_ctx* c, int32_t* f, size_t n, size_t stride, int mode, const uint8_t* flags, const uint8_t* sub_ok,
                          uint8_t* d_bitmap, uint8_t* d_gt, int* d_is_one) {
+  CHECK_LANES(c, stride);
   for (DevBuf& b : c->fe) HIPCHK(c, b.reserve(stride * 108 * 4));
   HIPCHK(c, c->fe_slots.reserve(stride * 108 * 4 * 10));
   int32_t* S = (int32_t*)c->fe_slots.p;
@@ -220,17 +234,18 @@ static int run_final_exp(blsbn254_ctx* c, int32_t* f, size_t n, size_t stride, i
 
 // ---------------- pairing / Miller loop / final exponentiation
 static int miller_to_ws(blsbn254_ctx* c, const uint8_t* d_g1, const uint8_t* d_g2, size_t n) {
+  CHECK_LANES(c, n);
   HIPCHK(c, c->f_ws.reserve(n * 108 * 4));
   HIPCHK(c, c->status.reserve(n));
   LAUNCH(c, "miller_1", k_miller_1, n, d_g1, d_g2, n, (int32_t*)c->f_ws.p, n, (uint8_t*)c->status.p);
   return 0;
 }
-static int decode_status_rc(blsbn254_ctx* c, size_t n) {
+static int decode_status_rc(blsbn254_ctx* c, const uint8_t* d_status, size_t n) {
   int bad;
-  int rc = first_bad(c, (const uint8_t*)c->status.p, n, 3, 3, &bad);
+  int rc = first_bad(c, d_status, n, 3, 3, &bad);
   if (rc) return rc;
   if (bad < 0) return 0;
-  uint8_t st; rc = read_status(c, (const uint8_t*)c->status.p, bad, &st);
+  uint8_t st; rc = read_status(c, d_status, bad, &st);
   if (rc) return rc;
   return (st & 1) ? BLSBN254_ERR_G2 : BLSBN254_ERR_G1;
 }
@@ -238,11 +253,16 @@ int blsbn254_pairing_batch_dev(blsbn254_ctx* c, const uint8_t* d_g1, const uint8
   if (!c || (n && (!d_g1 || !d_g2 || !d_gt))) return BLSBN254_E_ARG;
   if (n == 0) return 0;
   HIPCHK(c, hipSetDevice(c->device));
-  int rc = miller_to_ws(c, d_g1, d_g2, n);
-  if (rc) return rc;
-  rc = run_final_exp(c, (int32_t*)c->f_ws.p, n, n, 1, nullptr, nullptr, nullptr, d_gt, nullptr);
-  if (rc) return rc;
-  if (d_status) HIPCHK(c, hipMemcpyAsync(d_status, c->status.p, n, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(c, c->status_all.reserve(n));
+  for (size_t lo = 0; lo < n; lo += c->chunk) {
+    size_t m = n - lo < c->chunk ? n - lo : c->chunk;
+    int rc = miller_to_ws(c, d_g1 + 64 * lo, d_g2 + 128 * lo, m);
+    if (rc) return rc;
+    rc = run_final_exp(c, (int32_t*)c->f_ws.p, m, m, 1, nullptr, nullptr, nullptr, d_gt + 384 * lo, nullptr);
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync((uint8_t*)c->status_all.p + lo, c->status.p, m, hipMemcpyDeviceToDevice, c->stream));
+  }
+  if (d_status) HIPCHK(c, hipMemcpyAsync(d_status, c->status_all.p, n, hipMemcpyDeviceToDevice, c->stream));
   return 0;
 }
 int blsbn254_pairing_batch(blsbn254_ctx* c, const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t* gt) {
@@ -254,7 +274,7 @@ int blsbn254_pairing_batch(blsbn254_ctx* c, const uint8_t* g1, const uint8_t* g2
   HIPCHK(c, hipMemcpyAsync(c->in_b.p, g2, 128 * n, hipMemcpyHostToDevice, c->stream));
   int rc = blsbn254_pairing_batch_dev(c, (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_b.p, n, (uint8_t*)c->out.p, nullptr);
   if (rc) return rc;
-  rc = decode_status_rc(c, n);
+  rc = decode_status_rc(c, (const uint8_t*)c->status_all.p, n);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(gt, c->out.p, 384 * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -267,11 +287,14 @@ int blsbn254_miller_loop_batch(blsbn254_ctx* c, const uint8_t* g1, const uint8_t
   HIPCHK(c, c->in_a.reserve(64 * n)); HIPCHK(c, c->in_b.reserve(128 * n)); HIPCHK(c, c->out.reserve(384 * n));
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, g1, 64 * n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->in_b.p, g2, 128 * n, hipMemcpyHostToDevice, c->stream));
-  int rc = miller_to_ws(c, (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_b.p, n);
-  if (rc) return rc;
-  rc = decode_status_rc(c, n);
-  if (rc) return rc;
-  LAUNCH(c, "fp12_to_bytes", k_fp12_to_bytes, n, (const int32_t*)c->f_ws.p, n, n, (uint8_t*)c->out.p);
+  for (size_t lo = 0; lo < n; lo += c->chunk) {
+    size_t m = n - lo < c->chunk ? n - lo : c->chunk;
+    int rc = miller_to_ws(c, (const uint8_t*)c->in_a.p + 64 * lo, (const uint8_t*)c->in_b.p + 128 * lo, m);
+    if (rc) return rc;
+    rc = decode_status_rc(c, (const uint8_t*)c->status.p, m);
+    if (rc) return rc;
+    LAUNCH(c, "fp12_to_bytes", k_fp12_to_bytes, m, (const int32_t*)c->f_ws.p, m, m, (uint8_t*)c->out.p + 384 * lo);
+  }
   HIPCHK(c, hipMemcpyAsync(ml_out, c->out.p, 384 * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
@@ -292,13 +315,14 @@ static int product_tree(blsbn254_ctx* c, size_t n, const int32_t** result, size_
 int blsbn254_multi_miller_loop(blsbn254_ctx* c, const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t ml_out[384]) {
   if (!c || !ml_out || (n && (!g1 || !g2))) return BLSBN254_E_ARG;
   if (n == 0) { std::memset(ml_out, 0, 384); ml_out[31] = 1; return 0; }       // empty product = Fp12::ONE
+  CHECK_LANES(c, n);
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, c->in_a.reserve(64 * n)); HIPCHK(c, c->in_b.reserve(128 * n)); HIPCHK(c, c->out.reserve(384));
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, g1, 64 * n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->in_b.p, g2, 128 * n, hipMemcpyHostToDevice, c->stream));
   int rc = miller_to_ws(c, (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_b.p, n);
   if (rc) return rc;
-  rc = decode_status_rc(c, n);
+  rc = decode_status_rc(c, (const uint8_t*)c->status.p, n);
   if (rc) return rc;
   const int32_t* res; size_t rs;
   rc = product_tree(c, n, &res, &rs);
@@ -312,14 +336,18 @@ int blsbn254_final_exponentiation(blsbn254_ctx* c, const uint8_t* ml, size_t n, 
   if (!c || (n && (!ml || !gt))) return BLSBN254_E_ARG;
   if (n == 0) return 0;
   HIPCHK(c, hipSetDevice(c->device));
-  HIPCHK(c, c->in_a.reserve(384 * n)); HIPCHK(c, c->out.reserve(384 * n)); HIPCHK(c, c->f_ws.reserve(n * 108 * 4)); HIPCHK(c, c->status.reserve(n));
+  HIPCHK(c, c->in_a.reserve(384 * n)); HIPCHK(c, c->out.reserve(384 * n));
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, ml, 384 * n, hipMemcpyHostToDevice, c->stream));
-  LAUNCH(c, "fp12_from_bytes", k_fp12_from_bytes, n, (const uint8_t*)c->in_a.p, n, (int32_t*)c->f_ws.p, n, (uint8_t*)c->status.p);
-  int bad; int rc = first_bad(c, (const uint8_t*)c->status.p, n, 1, 1, &bad);
-  if (rc) return rc;
-  if (bad >= 0) return BLSBN254_ERR_GT;
-  rc = run_final_exp(c, (int32_t*)c->f_ws.p, n, n, 1, nullptr, nullptr, nullptr, (uint8_t*)c->out.p, nullptr);
-  if (rc) return rc;
+  for (size_t lo = 0; lo < n; lo += c->chunk) {
+    size_t m = n - lo < c->chunk ? n - lo : c->chunk;
+    HIPCHK(c, c->f_ws.reserve(m * 108 * 4)); HIPCHK(c, c->status.reserve(m));
+    LAUNCH(c, "fp12_from_bytes", k_fp12_from_bytes, m, (const uint8_t*)c->in_a.p + 384 * lo, m, (int32_t*)c->f_ws.p, m, (uint8_t*)c->status.p);
+    int bad; int rc = first_bad(c, (const uint8_t*)c->status.p, m, 1, 1, &bad);
+    if (rc) return rc;
+    if (bad >= 0) return BLSBN254_ERR_GT;
+    rc = run_final_exp(c, (int32_t*)c->f_ws.p, m, m, 1, nullptr, nullptr, nullptr, (uint8_t*)c->out.p + 384 * lo, nullptr);
+    if (rc) return rc;
+  }
   HIPCHK(c, hipMemcpyAsync(gt, c->out.p, 384 * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
@@ -380,8 +408,7 @@ int blsbn254_g2_check_batch(blsbn254_ctx* c, const uint8_t* g2, size_t n, uint8_
 
 // ---------------- verify
 // Workspace is ~7.4 KB per tuple (H, f, six final-exponentiation phase buffers, ten chain slots); batches
-// larger than VERIFY_CHUNK tuples are processed chunk by chunk so that any n fits the 288 GB of HBM.
-static const size_t VERIFY_CHUNK = (size_t)1 << 22;
+// larger than ctx->chunk (4 Mi) tuples are processed chunk by chunk so that any n fits the 288 GB of HBM.
 static int verify_chunk_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
                             const uint8_t* d_sigs, size_t n, uint32_t dl, uint8_t* d_bitmap) {
   HIPCHK(c, c->h_ws.reserve(n * 18 * 4)); HIPCHK(c, c->f_ws.reserve(n * 108 * 4));
@@ -398,8 +425,8 @@ int blsbn254_verify_batch_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8
   HIPCHK(c, hipSetDevice(c->device));
   uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
   if (rc) return rc;
-  for (size_t lo = 0; lo < n; lo += VERIFY_CHUNK) {        // chunk starts are multiples of 8: bitmap bytes do not straddle
-    size_t m = n - lo < VERIFY_CHUNK ? n - lo : VERIFY_CHUNK;
+  for (size_t lo = 0; lo < n; lo += c->chunk) {        // chunk starts are multiples of 8: bitmap bytes do not straddle
+    size_t m = n - lo < c->chunk ? n - lo : c->chunk;
     rc = verify_chunk_dev(c, d_pks + 128 * lo, d_msgs, d_off + lo, d_sigs + 64 * lo, m, dl, d_bitmap + lo / 8);
     if (rc) return rc;
   }
@@ -411,6 +438,7 @@ int blsbn254_verify_batch_rlc(blsbn254_ctx* c, const uint8_t* pks, const uint8_t
                               size_t n, const uint8_t* dst, size_t dst_len, const uint8_t seed[32], uint8_t* bm) {
   if (!c || !off || !seed || (n && (!pks || !sigs || !bm)) || (dst_len && !dst)) return BLSBN254_E_ARG;
   if (n == 0) return 0;
+  CHECK_LANES(c, n);
   if (n > ((size_t)1 << 26)) return BLSBN254_E_ARG;                 // one pass; split larger batches in the caller
   HIPCHK(c, hipSetDevice(c->device));
   uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
@@ -522,6 +550,7 @@ int blsbn254_aggregate_partial(blsbn254_ctx* c, const uint8_t* pks, const uint8_
   if (!c || !ml_out || !all_pks_ok || !off || (n && !pks) || (dst_len && !dst)) return BLSBN254_E_ARG;
   *all_pks_ok = 1;
   if (n == 0) { std::memset(ml_out, 0, 384); ml_out[31] = 1; return 0; }
+  CHECK_LANES(c, n);
   HIPCHK(c, hipSetDevice(c->device));
   uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
   if (rc) return rc;

@@ -58,6 +58,9 @@ const char* blsbn254_strerror(int code);
 const char* blsbn254_last_error(blsbn254_ctx* ctx); /* text of the last HIP error on this ctx */
 
 /* ---- primitives, 1:1 with the reference operator API ------------------------------------- */
+/* Size limits: entry points whose elements are independent (pairing_batch, miller_loop_batch, final_exponentiation,
+ * verify_batch*, pop_verify_batch) accept any n and process it in chunks of 4 Mi elements; the product-type ones
+ * (multi_miller_loop, aggregate_*, verify_batch_rlc) take at most 2^23 elements per call (BLSBN254_E_ARG beyond). */
 /* pairing(&G1Affine, &G2Affine) -> Gt, pairings.rs:760-802 (pairing::Engine::pairing :685-696).
  * Identity in either slot gives Gt::IDENTITY. */
 int blsbn254_pairing_batch(blsbn254_ctx* ctx, const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t* gt);

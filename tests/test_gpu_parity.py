@@ -447,3 +447,29 @@ def test_verify_batch_rlc_adversarial_pairs(eng, oracle, pyref, M):
     assert eng.verify_batch(pks, msgs, sigs, dst) == b"\x00"
     for t in range(4):
         assert eng.verify_batch_rlc(pks, msgs, sigs, dst, seed=bytes([t]) * 32) == b"\x00"
+
+
+def test_chunked_entry_points(oracle, pyref, M, monkeypatch):
+    """Batches larger than the per-launch chunk (4 Mi tuples in production; forced to 64 here through the
+    BLSBN254_CHUNK_LANES test knob) are processed chunk by chunk: same results as the one-launch path."""
+    monkeypatch.setenv("BLSBN254_CHUNK_LANES", "64")
+    e = M.Engine(0)
+    try:
+        n = 64 * 3 + 17
+        pks, msgs, sigs, exp = synth.make_batch(oracle, n, M.DEFAULT_DST, invalid_every=5, uniq=16)
+        assert e.verify_batch(pks, msgs, sigs, M.DEFAULT_DST) == synth.bitmap_of(exp)
+        rnd = random.Random(90)
+        G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+        m = 64 * 2 + 5
+        g1 = b"".join(oracle.g1_mul(G1, rnd.randrange(1, pyref.R)) for _ in range(m))
+        g2 = b"".join(oracle.g2_mul(G2, rnd.randrange(1, pyref.R)) for _ in range(m))
+        gt = e.pairing_batch(g1, g2, m)
+        assert gt == oracle.pairing_batch(g1, g2, m)
+        ml = e.miller_loop_batch(g1, g2, m)
+        assert ml == oracle.miller_loop_batch(g1, g2, m)
+        assert e.final_exponentiation(ml, m) == gt
+        bad = g1[:64 * 130] + b"\xff" * 32 + g1[64 * 130 + 32:]         # element 130 (third chunk): x >= p does not decode
+        with pytest.raises(M.InvalidG1Bytes):
+            e.pairing_batch(bad, g2, m)
+    finally:
+        e.close()
