@@ -7,13 +7,11 @@
 #include "kernels.h"
 using namespace bn;
 
-static __device__ const int8_t d_ate_naf[bnc::ATE_NAF_LEN] = BN_ATE_NAF_INIT;
-
 BN_KERNEL k_miller_1(const uint8_t* g1, const uint8_t* g2, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;      // 32-bit lane index, buffer-addressed workspace (see k_miller_verify.hip)
   if (i >= n) return;
   uint8_t st;
-  Fp12 f = lane_miller_1(g1 + 64 * (size_t)i, g2 + 128 * (size_t)i, d_ate_naf, bnc::ATE_NAF_LEN, st);
+  Fp12 f = lane_miller_1(g1 + 64 * (size_t)i, g2 + 128 * (size_t)i, st);
   fp12_store_limbs(Ws{f_ws, f_stride, i * 4u, true}, f);
   status[i] = st;
 }

@@ -7,8 +7,6 @@
 #include "kernels.h"
 using namespace bn;
 
-static __device__ const int8_t d_ate_naf[bnc::ATE_NAF_LEN] = BN_ATE_NAF_INIT;
-
 BN_KERNEL k_miller_hpk(const int32_t* h_ws, const uint8_t* pks, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* flags) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;      // 32-bit lane index, buffer-addressed workspaces (see k_miller_verify.hip)
   if (i >= n) return;
@@ -19,6 +17,6 @@ BN_KERNEL k_miller_hpk(const int32_t* h_ws, const uint8_t* pks, size_t n, int32_
   pk.inf = false;
   const Ws hw = {const_cast<int32_t*>(h_ws), n, i * 4u, true};
   G1A h; h.x = fp_load_mem(hw); h.y = fp_load_mem(ws_at(hw, 9)); h.inf = false;
-  fp12_store_limbs(Ws{f_ws, f_stride, i * 4u, true}, miller_loop_1(h, pk, d_ate_naf, bnc::ATE_NAF_LEN));
+  fp12_store_limbs(Ws{f_ws, f_stride, i * 4u, true}, miller_loop_1(h, pk));
   flags[i] = pk_ok ? 1 : 0;
 }

@@ -11,8 +11,6 @@
 #include "kernels.h"
 using namespace bn;
 
-static __device__ const int8_t d_ate_naf[bnc::ATE_NAF_LEN] = BN_ATE_NAF_INIT;
-
 BN_KERNEL k_miller_verify(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n, int32_t* f_ws, uint8_t* flags) {
   __shared__ int32_t inv_lds[72 * 256];          // each lane touches only its own column: no barrier needed
   // 32-bit lane index and buffer-addressed workspaces: no 64-bit per-lane value lives across the loop (a
@@ -22,7 +20,7 @@ BN_KERNEL k_miller_verify(const uint8_t* pks, const uint8_t* sigs, const int32_t
   const Ws hw = {const_cast<int32_t*>(h_ws), n, i * 4u, true};
   G1A h; h.x = fp_load_mem(hw); h.y = fp_load_mem(ws_at(hw, 9)); h.inf = false;
   uint8_t fl;
-  Fp12 f = lane_miller_verify_ws(pks + 128 * (size_t)i, sigs + 64 * (size_t)i, h, d_ate_naf, bnc::ATE_NAF_LEN, BN_NEG_G2_LINE_TABLE, fl,
+  Fp12 f = lane_miller_verify_ws(pks + 128 * (size_t)i, sigs + 64 * (size_t)i, h, BN_NEG_G2_LINE_TABLE, fl,
                                  Ws{inv_lds, 256, threadIdx.x * 4u, false});
   fp12_store_limbs(Ws{f_ws, n, i * 4u, true}, f);
   flags[i] = fl;

@@ -56,7 +56,7 @@ BN_FUNC bool lane_g2_check(const uint8_t* g2) {
 }
 
 // ---- Miller loops.  status bit0: g1 decoded, bit1: g2 decoded, bit2: either point is the identity.
-BN_FUNC Fp12 lane_miller_1(const uint8_t* g1, const uint8_t* g2, const int8_t* naf, int naf_len, uint8_t& status) {
+BN_FUNC Fp12 lane_miller_1(const uint8_t* g1, const uint8_t* g2, uint8_t& status) {
   bool ok1, ok2;
   G1A p = g1_decode(g1, ok1);
   G2A q = g2_decode(g2, ok2);
@@ -69,7 +69,7 @@ BN_FUNC Fp12 lane_miller_1(const uint8_t* g1, const uint8_t* g2, const int8_t* n
   G2A gq; gq.x = fp2_const(bnc::G2_GEN_X); gq.y = fp2_const(bnc::G2_GEN_Y); gq.inf = false;
   p.x = fp_select(bad, gp.x, p.x); p.y = fp_select(bad, gp.y, p.y);
   q.x = fp2_select(bad, gq.x, q.x); q.y = fp2_select(bad, gq.y, q.y);
-  Fp12 f = miller_loop_1(p, q, naf, naf_len);
+  Fp12 f = miller_loop_1(p, q);
   Fp12 one = fp12_one();
   f.c0 = {fp2_select(bad, one.c0.c0, f.c0.c0), fp2_select(bad, one.c0.c1, f.c0.c1), fp2_select(bad, one.c0.c2, f.c0.c2)};
   f.c1 = {fp2_select(bad, one.c1.c0, f.c1.c0), fp2_select(bad, one.c1.c1, f.c1.c1), fp2_select(bad, one.c1.c2, f.c1.c2)};
@@ -78,7 +78,7 @@ BN_FUNC Fp12 lane_miller_1(const uint8_t* g1, const uint8_t* g2, const int8_t* n
 // verify: f = ML(sig, -G2gen) * ML(H, pk); flags = FLAG_SIG_OK | FLAG_PK_OK when decodable, on curve, non-identity
 // Variant that first writes the validated operands to the limb-major workspace `inv` (72 limbs per tuple) and
 // runs the loop that re-loads them per use (miller_loop_verify_ws).
-BN_FUNC Fp12 lane_miller_verify_ws(const uint8_t* pk_b, const uint8_t* sig_b, const G1A& h, const int8_t* naf, int naf_len,
+BN_FUNC Fp12 lane_miller_verify_ws(const uint8_t* pk_b, const uint8_t* sig_b, const G1A& h,
                                    const int32_t (*table)[54], uint8_t& flags, const Ws& inv) {
   bool oks, okp;
   G1A sig = g1_decode(sig_b, oks);
@@ -92,9 +92,9 @@ BN_FUNC Fp12 lane_miller_verify_ws(const uint8_t* pk_b, const uint8_t* sig_b, co
   fp2_store_mem(ws_at(inv, 36), fp2_norm(fp2_select(pk_ok, pk.x, fp2_const(bnc::G2_GEN_X))));
   fp2_store_mem(ws_at(inv, 54), fp2_norm(fp2_select(pk_ok, pk.y, fp2_const(bnc::G2_GEN_Y))));
   BN_MEM_FENCE;
-  return miller_loop_verify_ws(inv, naf, naf_len, table);
+  return miller_loop_verify_ws(inv, table);
 }
-BN_FUNC Fp12 lane_miller_verify(const uint8_t* pk_b, const uint8_t* sig_b, const G1A& h, const int8_t* naf, int naf_len,
+BN_FUNC Fp12 lane_miller_verify(const uint8_t* pk_b, const uint8_t* sig_b, const G1A& h,
                                      const int32_t (*table)[54], uint8_t& flags) {
   bool oks, okp;
   G1A sig = g1_decode(sig_b, oks);
@@ -107,7 +107,7 @@ BN_FUNC Fp12 lane_miller_verify(const uint8_t* pk_b, const uint8_t* sig_b, const
   G1A gp; gp.x = fp_one(); gp.y = fp_norm(fp_add(fp_one(), fp_one())); gp.inf = false;
   sig.x = fp_select(sig_ok, sig.x, gp.x); sig.y = fp_select(sig_ok, sig.y, gp.y);
   pk.x = fp2_select(pk_ok, pk.x, fp2_const(bnc::G2_GEN_X)); pk.y = fp2_select(pk_ok, pk.y, fp2_const(bnc::G2_GEN_Y));
-  return miller_loop_verify(sig, h, pk, naf, naf_len, table);
+  return miller_loop_verify(sig, h, pk, table);
 }
 
 }  // namespace bn

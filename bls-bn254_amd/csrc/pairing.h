@@ -83,16 +83,32 @@ BN_INL Line line_from_table(const int32_t* t) {                  // 54 strict li
   return {fp2_from_limbs(t), fp2_from_limbs(t + 18), fp2_from_limbs(t + 36)};
 }
 
+// Digit j of NAF(6x+2), from two compile-time bit masks (non-zero, negative): scalar ALU only.  Read from the digit
+// array in memory, each loop iteration ended in an exposed global load (~1.5 us per iteration at one wave per SIMD).
+constexpr uint64_t ate_naf_mask(int word, bool neg) {
+  uint64_t m = 0;
+  for (int i = 0; i < 64; ++i) {
+    int j = 64 * word + i;
+    if (j < bnc::ATE_NAF_LEN && (neg ? bnc::ATE_NAF[j] < 0 : bnc::ATE_NAF[j] != 0)) m |= (uint64_t)1 << i;
+  }
+  return m;
+}
+BN_INL int ate_naf_digit(int j) {
+  constexpr uint64_t nz0 = ate_naf_mask(0, false), nz1 = ate_naf_mask(1, false), ng0 = ate_naf_mask(0, true), ng1 = ate_naf_mask(1, true);
+  const uint64_t nz = j < 64 ? nz0 : nz1, ng = j < 64 ? ng0 : ng1;
+  const int b = j & 63;
+  return ((nz >> b) & 1) ? (((ng >> b) & 1) ? -1 : 1) : 0;
+}
 // One-pair Miller loop f_{6x+2,Q}(P) * l_{T,pi(Q)}(P) * l_{T+pi(Q),-pi^2(Q)}(P)
-BN_FUNC Fp12 miller_loop_1(const G1A& p, const G2A& q, const int8_t* naf, int naf_len) {
+BN_FUNC Fp12 miller_loop_1(const G1A& p, const G2A& q) {
   BN_CTX;
   Fp12 f = fp12_one();
   G2J T = {q.x, q.y, fp2_one()};
   Fp2 nqy = fp2_norm(fp2_neg(q.y));
-  for (int j = naf_len - 2; j >= 0; --j) {
+  for (int j = bnc::ATE_NAF_LEN - 2; j >= 0; --j) {
     f = fp12_sqr(f);
     f = ell(f, doubling_step(T), p.x, p.y);
-    int d = naf[j];
+    int d = ate_naf_digit(j);
     if (d != 0) f = ell(f, addition_step(T, q.x, d > 0 ? q.y : nqy), p.x, p.y);
   }
   Fp2 g2 = fp2_const(bnc::GAMMA1[1]), g3 = fp2_const(bnc::GAMMA1[2]);
@@ -106,18 +122,18 @@ BN_FUNC Fp12 miller_loop_1(const G1A& p, const G2A& q, const int8_t* naf, int na
 
 // Two-pair loop of the verify equation: e(sig, -G2gen) * e(H, pk), the first pair's lines read from
 // the precomputed table (uniform address: every lane of the wave reads the same entry).
-BN_FUNC Fp12 miller_loop_verify(const G1A& sig, const G1A& h, const G2A& pk, const int8_t* naf, int naf_len,
+BN_FUNC Fp12 miller_loop_verify(const G1A& sig, const G1A& h, const G2A& pk,
                                      const int32_t (*table)[54]) {
   BN_CTX;
   Fp12 f = fp12_one();
   G2J T = {pk.x, pk.y, fp2_one()};
   Fp2 nqy = fp2_norm(fp2_neg(pk.y));
   int ti = 0;
-  for (int j = naf_len - 2; j >= 0; --j) {
+  for (int j = bnc::ATE_NAF_LEN - 2; j >= 0; --j) {
     f = fp12_sqr(f);
     f = ell(f, line_from_table(table[ti++]), sig.x, sig.y);
     f = ell(f, doubling_step(T), h.x, h.y);
-    int d = naf[j];
+    int d = ate_naf_digit(j);
     if (d != 0) {
       f = ell(f, line_from_table(table[ti++]), sig.x, sig.y);
       f = ell(f, addition_step(T, pk.x, d > 0 ? pk.y : nqy), h.x, h.y);
@@ -139,21 +155,21 @@ BN_FUNC Fp12 miller_loop_verify(const G1A& sig, const G1A& h, const G2A& pk, con
 // re-loaded where they are used (once per line); BN_OPAQUE hides the lane offset from the optimiser in every
 // iteration so the loads are not hoisted back out of the loop.  Frees 90 of the 256 architectural VGPRs for f, T
 // and the temporaries of the current product.
-BN_FUNC Fp12 miller_loop_verify_ws(const Ws& inv, const int8_t* naf, int naf_len, const int32_t (*table)[54]) {
+BN_FUNC Fp12 miller_loop_verify_ws(const Ws& inv, const int32_t (*table)[54]) {
   Fp12 f = fp12_one();
   G2J T = {fp2_load_mem(ws_at(inv, 36)), fp2_load_mem(ws_at(inv, 54)), fp2_one()};
   int ti = 0;
   Ws p = inv;
   // per step: the variable line first (T is the register-hungry part), then both lines are scaled and folded into f
   // as one product (ell2): 23 Fp2 products instead of 26
-  for (int j = naf_len - 2; j >= 0; --j) {
+  for (int j = bnc::ATE_NAF_LEN - 2; j >= 0; --j) {
     f = fp12_sqr(f);
     BN_OPAQUE(p);
     Fp sx = fp_load_mem(p), sy = fp_load_mem(ws_at(p, 9)), hx = fp_load_mem(ws_at(p, 18)), hy = fp_load_mem(ws_at(p, 27));
     BN_SCHED_BARRIER;                 // the four LDS reads are issued here; the doubling step hides their latency
     Line l = doubling_step(T);
     f = ell2(f, line_from_table(table[ti++]), sx, sy, l, hx, hy);
-    int d = naf[j];
+    int d = ate_naf_digit(j);
     if (d != 0) {
       BN_OPAQUE(p);
       Fp2 qy = fp2_load_mem(ws_at(p, 54));

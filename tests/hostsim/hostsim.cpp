@@ -40,7 +40,7 @@ void hs_hash_to_scalar(const uint8_t* msg, size_t len, const uint8_t* dst, uint3
 
 void hs_miller1(const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* status) {
   uint8_t st;
-  Fp12 f = lane_miller_1(g1, g2, bnc::ATE_NAF, bnc::ATE_NAF_LEN, st);
+  Fp12 f = lane_miller_1(g1, g2, st);
   *status = st;
   fp12_to_be(out, f);
 }
@@ -53,7 +53,7 @@ int hs_final_exp(const uint8_t* in, uint8_t* out) {
 }
 void hs_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* out) {
   uint8_t st;
-  Fp12 f = lane_miller_1(g1, g2, bnc::ATE_NAF, bnc::ATE_NAF_LEN, st);
+  Fp12 f = lane_miller_1(g1, g2, st);
   fp12_to_be(out, final_exponentiation(f));
 }
 int hs_expx_chain_matches(const uint8_t* in) {      // addition chain == binary ladder on a cyclotomic element
@@ -124,7 +124,7 @@ int hs_verify(const uint8_t* pk, const uint8_t* msg, size_t len, const uint8_t* 
               uint8_t* ml_out) {
   G1A h = lane_hash_to_g1(msg, len, dst, dst_len);
   uint8_t flags;
-  Fp12 f = lane_miller_verify(pk, sig, h, bnc::ATE_NAF, bnc::ATE_NAF_LEN, BN_NEG_G2_LINE_TABLE, flags);
+  Fp12 f = lane_miller_verify(pk, sig, h, BN_NEG_G2_LINE_TABLE, flags);
   if (ml_out) fp12_to_be(ml_out, f);
   bool sub = lane_g2_check(pk);
   bool one = fp12_is_one(final_exponentiation(f));
@@ -135,7 +135,7 @@ void hs_miller_verify_only(const uint8_t* pk, const uint8_t* sig, const uint8_t*
   bool ok; G1A h = g1_decode(h64, ok);
   uint8_t flags;
   check_stats() = CheckStats();
-  Fp12 f = lane_miller_verify(pk, sig, h, bnc::ATE_NAF, bnc::ATE_NAF_LEN, BN_NEG_G2_LINE_TABLE, flags);
+  Fp12 f = lane_miller_verify(pk, sig, h, BN_NEG_G2_LINE_TABLE, flags);
   if (ml_out) fp12_to_be(ml_out, f);
 }
 // the workspace-reload variant of the verify Miller loop (what k_miller_verify runs)
@@ -143,7 +143,7 @@ void hs_miller_verify_ws(const uint8_t* pk, const uint8_t* sig, const uint8_t* h
   bool ok; G1A h = g1_decode(h64, ok);
   uint8_t flags;
   static int32_t inv[72];
-  Fp12 f = lane_miller_verify_ws(pk, sig, h, bnc::ATE_NAF, bnc::ATE_NAF_LEN, BN_NEG_G2_LINE_TABLE, flags, Ws{inv, 1, 0, false});
+  Fp12 f = lane_miller_verify_ws(pk, sig, h, BN_NEG_G2_LINE_TABLE, flags, Ws{inv, 1, 0, false});
   fp12_to_be(ml_out, f);
   *flags_out = flags;
 }
