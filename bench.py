@@ -156,7 +156,7 @@ def main():
         }
         if not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 16)
-            sample = 256 * threads
+            sample = 512 * threads          # ~20 CPU-seconds of oracle work (~1.2 s wall on 16 threads)
             spk, smsg, ssig, sexp = synth.make_batch(O, sample, dst, invalid_every=INVALID_EVERY, uniq=UNIQ)
             t1 = time.perf_counter()
             bm = O.verify_batch(spk, smsg, ssig, dst, nthreads=threads)
