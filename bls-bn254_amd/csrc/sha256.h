@@ -10,8 +10,9 @@ namespace bn {
 
 struct Sha256 {
   uint32_t h[8];
-  uint32_t w[16];      // current block, big-endian words
-  uint32_t fill;       // bytes in w
+  uint32_t w[16];      // current block, big-endian words (complete words only)
+  uint32_t cur;        // the word being assembled
+  uint32_t fill;       // bytes taken into the current block
   uint64_t total;
 };
 
@@ -48,16 +49,17 @@ BN_FUNC void sha256_init(Sha256& s) {
   s.h[0] = 0x6a09e667; s.h[1] = 0xbb67ae85; s.h[2] = 0x3c6ef372; s.h[3] = 0xa54ff53a;
   s.h[4] = 0x510e527f; s.h[5] = 0x9b05688c; s.h[6] = 0x1f83d9ab; s.h[7] = 0x5be0cd19;
   for (int i = 0; i < 16; ++i) s.w[i] = 0;
-  s.fill = 0; s.total = 0;
+  s.cur = 0; s.fill = 0; s.total = 0;
 }
+// One byte: assembled in a register, the block array is written once per completed word (it is indexed by a
+// run-time value, so it lives in scratch: a read-modify-write per byte was an exposed scratch round trip per byte).
 BN_FUNC void sha256_byte(Sha256& s, uint8_t b) {
-  uint32_t k = s.fill >> 2, sh = 24 - 8 * (s.fill & 3);
-  s.w[k] |= (uint32_t)b << sh;
+  s.cur = (s.cur << 8) | b;
   ++s.fill; ++s.total;
-  if (s.fill == 64) {
-    sha256_compress(s.h, s.w);
-    for (int i = 0; i < 16; ++i) s.w[i] = 0;
-    s.fill = 0;
+  if ((s.fill & 3) == 0) {
+    s.w[(s.fill >> 2) - 1] = s.cur;
+    s.cur = 0;
+    if (s.fill == 64) { sha256_compress(s.h, s.w); s.fill = 0; }
   }
 }
 BN_FUNC void sha256_update(Sha256& s, const uint8_t* p, size_t n) { for (size_t i = 0; i < n; ++i) sha256_byte(s, p[i]); }
