@@ -222,10 +222,9 @@ static int run_final_exp(blsbn254_ctx* c, int32_t* f, size_t n, size_t stride, i
   int32_t *X = (int32_t*)c->fe[0].p, *A = (int32_t*)c->fe[1].p, *B = (int32_t*)c->fe[2].p, *C = (int32_t*)c->fe[3].p,
           *B2 = (int32_t*)c->fe[4].p, *D = (int32_t*)c->fe[5].p;
   LAUNCH(c, "fe_easy", k_fe_easy, n, (const int32_t*)f, f, n, stride);                       // t (in place)
-  LAUNCH(c, "fe_expx", k_fe_expx, n, (const int32_t*)f, X, S, n, stride);
-  LAUNCH(c, "fe_h1", k_fe_h1, n, (const int32_t*)X, A, B, n, stride);
-  LAUNCH(c, "fe_expx", k_fe_expx, n, (const int32_t*)B, X, S, n, stride);
-  LAUNCH(c, "fe_h2", k_fe_h2, n, (const int32_t*)X, (const int32_t*)B, C, B2, D, n, stride);
+  // t^x three times; the glue steps fe_h1 / fe_h2 are computed by the first two launches themselves (k_fe_expx_tail.hip)
+  LAUNCH(c, "fe_expx_h1", k_fe_expx_h1, n, (const int32_t*)f, S, n, stride, A, B);
+  LAUNCH(c, "fe_expx_h2", k_fe_expx_h2, n, (const int32_t*)B, S, n, stride, B, C, B2, D);
   LAUNCH(c, "fe_expx", k_fe_expx, n, (const int32_t*)D, X, S, n, stride);
   LAUNCH(c, "fe_h3", k_fe_h3, n, (const int32_t*)f, (const int32_t*)A, (const int32_t*)C, (const int32_t*)B2, (const int32_t*)X, S, n, stride,
          flags, sub_ok, d_bitmap, d_gt, d_is_one, mode);

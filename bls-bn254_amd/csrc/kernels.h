@@ -20,8 +20,8 @@ BN_KERNEL k_miller_hpk(const int32_t* h_ws, const uint8_t* pks, size_t n, int32_
 BN_KERNEL k_miller_verify(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n, int32_t* f_ws, uint8_t* flags);
 BN_KERNEL k_fe_easy(const int32_t* in, int32_t* out, size_t n, size_t stride);
 BN_KERNEL k_fe_expx(const int32_t* in, int32_t* out, int32_t* slots, size_t n, size_t stride);
-BN_KERNEL k_fe_h1(const int32_t* x0, int32_t* a_out, int32_t* b_out, size_t n, size_t stride);
-BN_KERNEL k_fe_h2(const int32_t* x0, const int32_t* b_in, int32_t* c_out, int32_t* b2_out, int32_t* d2_out, size_t n, size_t stride);
+BN_KERNEL k_fe_expx_h1(const int32_t* in, int32_t* slots, size_t n, size_t stride, int32_t* a_out, int32_t* b_out);
+BN_KERNEL k_fe_expx_h2(const int32_t* in, int32_t* slots, size_t n, size_t stride, int32_t* b_in, int32_t* c_out, int32_t* b2_out, int32_t* d2_out);
 BN_KERNEL k_fe_h3(const int32_t* t, const int32_t* a, const int32_t* c, const int32_t* b2, const int32_t* x0, int32_t* tmp, size_t n, size_t stride,
                   const uint8_t* flags, const uint8_t* sub_ok, uint8_t* bitmap, uint8_t* gt_bytes, int* is_one, int mode);
 BN_KERNEL k_fp12_from_bytes(const uint8_t* in, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status);

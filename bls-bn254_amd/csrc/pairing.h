@@ -364,4 +364,20 @@ BN_FUNC Fp12 fe_h3_loop(const Ws* src, const Ws& tmp, const Ws* park) {
   return r;
 }
 
+// fe_h1 / fe_h2 as tails of the t^x phase kernels (k_fe_expx_tail.hip): computed right after the chain from the value
+// still in registers, results written to the limb-major phase buffers (normalised limbs).  Same values as fe_h1 / fe_h2.
+BN_FUNC void fe_h1_tail(const Fp12& x0, const Ws& a_out, const Ws& b_out, const Ws* park) {
+  Fp12 a = fp12_cyclotomic_sqr(fp12_conj(x0));
+  fp12_store_mem(a_out, a);
+  BN_MEM_FENCE;
+  fp12_store_mem(b_out, fp12_mul_mem(fp12_cyclotomic_sqr(a), a_out, park));            // b = a^2 * a
+}
+BN_FUNC void fe_h2_tail(const Fp12& x0, const Ws& b_in, const Ws& c_out, const Ws& b2_out, const Ws& d2_out, const Ws* park) {
+  fp12_store_mem(c_out, fp12_conj(x0));                                                   // c
+  BN_MEM_FENCE;
+  fp12_store_mem(b2_out, fp12_conj(fp12_mul_mem(x0, b_in, park)));                        // b2 = c conj(b) = conj(x0 b)
+  BN_MEM_FENCE;
+  fp12_store_mem(d2_out, fp12_cyclotomic_sqr(fp12_load_mem(c_out)));                      // d2 = c^2
+}
+
 }  // namespace bn

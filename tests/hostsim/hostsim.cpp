@@ -89,6 +89,27 @@ int hs_fe_h3_loop_matches(const uint8_t* in) {      // interpreter form of h3 (t
   fp12_to_be(b1, r1); fp12_to_be(bb, r2);
   return std::memcmp(b1, bb, 384) == 0;
 }
+int hs_fe_tails_match(const uint8_t* in) {          // fe_h1 / fe_h2 computed as tails of the t^x kernels == the separate steps
+  bool ok;
+  Fp12 t = fe_easy(fp12_from_be(in, ok)), a, b, c, b2, d2;
+  Fp12 x1 = cyclotomic_exp_x(t);
+  fe_h1(x1, a, b);
+  Fp12 x2 = cyclotomic_exp_x(b);
+  fe_h2(x2, b, c, b2, d2);
+  static int32_t park[108], e[5][108];
+  const Ws pk = {park, 1, 0, false};
+  Ws w[5] = {{e[0], 1, 0, false}, {e[1], 1, 0, false}, {e[2], 1, 0, false}, {e[3], 1, 0, false}, {e[4], 1, 0, false}};
+  uint8_t want[384], got[384];
+  bool same = true;
+  fe_h1_tail(x1, w[0], w[1], &pk);                                         // a, b
+  fp12_to_be(want, a); fp12_to_be(got, fp12_load_mem(w[0])); same &= std::memcmp(want, got, 384) == 0;
+  fp12_to_be(want, b); fp12_to_be(got, fp12_load_mem(w[1])); same &= std::memcmp(want, got, 384) == 0;
+  fe_h2_tail(x2, w[1], w[2], w[3], w[4], &pk);                             // c, b2, d2
+  fp12_to_be(want, c); fp12_to_be(got, fp12_load_mem(w[2])); same &= std::memcmp(want, got, 384) == 0;
+  fp12_to_be(want, b2); fp12_to_be(got, fp12_load_mem(w[3])); same &= std::memcmp(want, got, 384) == 0;
+  fp12_to_be(want, d2); fp12_to_be(got, fp12_load_mem(w[4])); same &= std::memcmp(want, got, 384) == 0;
+  return same;
+}
 void hs_fp12_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
   bool o1, o2;
   Fp12 x = fp12_from_be(a, o1), y = fp12_from_be(b, o2);

@@ -62,6 +62,7 @@ def test_pairing_path_bit_exact_and_bounded(hs, oracle, pyref, kats):
         hs.hs_pairing(p, q, gt); assert gt.raw == oracle.pairing_batch(p, q, 1)
     assert hs.hs_expx_chain_matches(oracle.miller_loop_batch(G1, G2, 1)) == 1       # t^x: addition chain == binary ladder
     assert hs.hs_fe_h3_loop_matches(oracle.miller_loop_batch(G1, G2, 1)) == 1       # interpreter h3 (kernel) == register h3
+    assert hs.hs_fe_tails_match(oracle.miller_loop_batch(G1, G2, 1)) == 1           # fe_h1 / fe_h2 as tails of the t^x kernels
     ident = bytes(32) + (1).to_bytes(32, "big")
     hs.hs_miller1(ident, G2, ml, ctypes.byref(st))
     assert st.value == 7 and ml.raw == (1).to_bytes(32, "big") + bytes(352)
