@@ -7,9 +7,14 @@
 A step = one pass of the whole verify hot path (hash-to-G1, G2 subgroup check, 2-pair Miller loop,
 final exponentiation, bitmap) over one synthetic batch per GPU, inputs already resident in HBM
 (PCIe-inclusive rate: DESIGN.md).  Workload at N = 1 is BASELINE.json configs[1]: 262144 batched
-single-signature verifies on one MI355X; at N > 1 every rank gets its own 262144 (weak scaling,
-configs[3] shape) and the ranks exchange only the validity bitmap (RCCL all-reduce).
+single-signature verifies on one MI355X; at N > 1 it is configs[3]: every rank gets its own 1048576
+(8 M over 8 GPUs, weak scaling) and the ranks exchange only the validity bitmap (RCCL all-reduce).
 Rank 0 prints ONE JSON line.
+
+Launching: with WORLD_SIZE set (torch.distributed.run) this process is one rank and WORLD_SIZE must equal
+--gpus.  With WORLD_SIZE unset and --gpus N > 1 this process starts the N ranks itself as child processes
+(python -m torch.distributed.run ... bench.py ...) BEFORE anything touches the GPU, waits, and relays their
+output and exit code -- it never re-executes a process that has initialised the GPU.
 """
 import argparse
 import json
@@ -20,7 +25,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_PER_GPU = 262144
+N_PER_GPU = 262144         # BASELINE configs[1]: one GPU
+N_PER_GPU_MULTI = 1048576  # BASELINE configs[3]: 8 M tuples over 8 GPUs
 UNIQ = 64                 # cpu_baseline sample only: distinct tuples signed by the CPU oracle, tiled
 INVALID_EVERY = 64        # 1/64 of the tuples are corrupted
 FP_MUL_MADS = 136         # 32x32->64 MADs of one 8x32-bit-limb Montgomery multiplication (2n^2 + n)
@@ -31,18 +37,47 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--tuples-per-gpu", dest="n", type=int, default=N_PER_GPU, help="tuples per GPU")
+    ap.add_argument("--tuples-per-gpu", dest="n", type=int, default=0,
+                    help="tuples per GPU (default: 262144 at --gpus 1 = configs[1], 1048576 at --gpus N > 1 = configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--all-on-device0", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench: --gpus must be >= 1")
+    if args.n <= 0:
+        args.n = N_PER_GPU if args.gpus == 1 else N_PER_GPU_MULTI
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)
+    run_rank(args)
+
+
+def spawn_ranks(args):
+    """Parent of an N-rank run: no torch.cuda / HIP call happens in this process."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    rc = subprocess.call(cmd, env=env)      # children inherit stdout / stderr: rank 0's JSON line goes straight through
+    sys.exit(rc)
+
+
+def run_rank(args):
     import numpy as np
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench: WORLD_SIZE=%d but --gpus %d (launch with --nproc-per-node equal to --gpus)" % (world, args.gpus))
     local_rank = 0 if args.all_on_device0 else int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -65,15 +100,16 @@ def main():
     n_total = n * world
     lo = rank * n
 
-    # synthetic batch: n UNIQUE tuples, key pool of 1024, signed by the engine's own GPU signing
-    # kernels and spot-checked at 1000 random indices against the CPU oracle; 1/64 corrupted in five ways
-    pks, msgs, sigs, exp = synth.make_batch_gpu(eng, O, n, dst, pool=1024, invalid_every=INVALID_EVERY, spot=1000)
+    # synthetic batch: n UNIQUE tuples per rank (global indices lo..lo+n), key pool of 1024, signed by the
+    # engine's own GPU signing kernels and spot-checked at 1000 random indices against the CPU oracle; 1/64 corrupted
+    pks, msgs, sigs, exp = synth.make_batch_gpu(eng, O, n, dst, pool=1024, invalid_every=INVALID_EVERY, spot=1000, base=lo)
     data, off = M.engine.pack_messages(msgs)
     t_pk = torch.frombuffer(bytearray(pks), dtype=torch.uint8).to(dev)
     t_sg = torch.frombuffer(bytearray(sigs), dtype=torch.uint8).to(dev)
     t_ms = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
     t_off = torch.from_numpy(off.astype(np.int64)).to(dev)
     t_bm = torch.zeros((n + 7) // 8, dtype=torch.uint8, device=dev)
+    del pks, sigs, data, msgs
     torch.cuda.synchronize()
 
     def step():
@@ -112,9 +148,9 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        # every rank holds the same full bitmap: check it against the tiled expectation
+        # every rank holds the same full bitmap: check it against the closed-form expectation over all global indices
         full = sharded.words_to_bitmap_bytes(words.cpu().numpy(), n_total)
-        if full != synth.bitmap_of(exp * world):
+        if full != synth.bitmap_of(synth.expected_bits(n_total, INVALID_EVERY)):
             raise SystemExit("bench: all-reduced bitmap differs from the expected pattern")
 
     if rank == 0:
@@ -126,56 +162,88 @@ def main():
         mil_ms = mil["total_ms"] / max(mil["launches"], 1)
         mil_mads = (core[0] + core[1]) * FP_MUL_MADS * n
         achieved = mil_mads / (mil_ms * 1e-3) / 1e12
-        peak = eng.valu_peak() / 1e12
+        probe = eng.valu_probe()
+        peak = probe["mad_per_s"] / 1e12
+        ceiling = probe["issue_ceiling_per_s"] / 1e12
         kern = {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in prof.items()}
         # HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes of this build
-        traffic, traffic_note = None, "no PMC profile committed"
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tpath) and n == N_PER_GPU:
-            tj = json.load(open(tpath))
-            if "k_miller_verify" in tj.get("kernels", {}):
-                traffic = tj["kernels"]["k_miller_verify"]["hbm_bytes_per_launch"]
-                traffic_note = ("PMC FETCH_SIZE/WRITE_SIZE of the same kernel at the same batch size (profiles/r01_traffic.json): "
-                                "%.1f KB per tuple against ~1.4 KB algorithmic (inputs 0.3 KB, H 72 B, f out 432 B, line table from cache)"
-                                % (traffic / n / 1024.0))
+        traffic, traffic_note = None, "no PMC profile committed for this batch size"
+        for tname in ("r02_traffic.json", "r01_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath) and n == N_PER_GPU:
+                tj = json.load(open(tpath))
+                if "k_miller_verify" in tj.get("kernels", {}):
+                    traffic = tj["kernels"]["k_miller_verify"]["hbm_bytes_per_launch"]
+                    traffic_note = ("PMC FETCH_SIZE/WRITE_SIZE of the same kernel at the same batch size (profiles/%s): "
+                                    "%.1f KB per tuple against ~1.4 KB algorithmic (inputs 0.3 KB, H 72 B, f out 432 B, line table from cache)"
+                                    % (tname, traffic / n / 1024.0))
+                    break
+        if world == 1:
+            wl = "BASELINE configs[1]"
+        else:
+            wl = "BASELINE configs[3] shape: %d tuples sharded over %d ranks, bitmap all-reduce (%s)" % (
+                n_total, world, "RCCL over xGMI" if args.backend == "nccl" else args.backend)
         out = {
             "metric": "BN254 pairings/sec (= BLS verifies/sec)", "value": round(value, 1), "unit": "verifies/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-            "config": {"workload": "%d batched single-sig BLS verifies per GPU (BASELINE configs[1]%s), unique 32-byte messages, "
+            "config": {"workload": "%d batched single-sig BLS verifies per GPU (%s), unique 32-byte messages, "
                                    "1024-key pool, 1/64 invalid tuples; hash-to-G1 + G2 subgroup check + 2-pair Miller loop + final exp"
-                                   % (n, "" if world == 1 else " x %d ranks, bitmap all-reduce over RCCL" % world),
+                                   % (n, wl),
                        "tuples_per_gpu": n, "tuples_total": n_total},
             "roofline": {"bound": "valu", "kernel": "k_miller_verify", "achieved": round(achieved, 4), "peak": round(peak, 3),
-                         "unit": "T int-MAD/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
-                         "note": "achieved = (%d+%d) Fp-mul x %d MAD x %d tuples / %.3f ms (HIP events on the engine stream); "
-                                 "peak = v_mad_u64_u32 rate measured in this run (blsbn254_valu_peak); the path is bound by VALU integer "
-                                 "issue, not HBM (algorithmic traffic ~1.4 KB/verify) and not MFMA" % (core[0], core[1], FP_MUL_MADS, n, mil_ms)},
+                         "unit": "T int-MAD/s", "frac": round(achieved / peak, 4),
+                         "peak_issue_ceiling": round(ceiling, 3), "frac_issue_ceiling": round(achieved / ceiling, 4),
+                         "peak_vop2_measured": round(probe["vop2_per_s"] / 1e12, 3),
+                         "clock_ghz_under_probe": round(probe["clock_hz_mad"] / 1e9, 3),
+                         "traffic": traffic, "traffic_note": traffic_note,
+                         "note": "achieved = (%d+%d) Fp-mul x %d MAD x %d tuples / %.3f ms (HIP events on the engine stream).  Counting "
+                                 "convention: Fp-mul = the CPU oracle's textbook count for the 2-pair loop (squarings count 1); MADs per "
+                                 "Fp-mul = 136, the 8x32-bit-limb Montgomery product of SURVEY.md 8d.  The kernel's own algorithm needs "
+                                 "fewer products (~11600: both lines of a step are folded into f as one product) but executes more MADs "
+                                 "per product (9x29-bit lazy limbs: 162, 243 per double product): ~2.0 M executed vs %.2f M counted per "
+                                 "tuple.  peak = v_mad_u64_u32 rate measured in this run at 4 waves/SIMD (blsbn254_valu_probe); "
+                                 "peak_issue_ceiling = CUs x 4 SIMDs x 16 lanes x the clock held under the probe (one VALU instruction "
+                                 "per 4 cycles per SIMD, MI355X_MICROARCH.md).  The path is bound by VALU integer issue, not HBM "
+                                 "(algorithmic traffic ~1.4 KB/verify) and not MFMA"
+                                 % (core[0], core[1], FP_MUL_MADS, n, mil_ms, (core[0] + core[1]) * FP_MUL_MADS / 1e6)},
             "kernel_ms": kern,
             "algorithmic_fp_mul_per_verify": {"miller_variable_pair": core[0], "miller_fixed_pair_lines": core[1], "final_exp": core[2]},
         }
-        if not args.no_cpu_baseline:
-            threads = min(os.cpu_count() or 1, 16)
-            sample = 512 * threads          # ~20 CPU-seconds of oracle work (~1.2 s wall on 16 threads)
-            spk, smsg, ssig, sexp = synth.make_batch(O, sample, dst, invalid_every=INVALID_EVERY, uniq=UNIQ)
-            t1 = time.perf_counter()
-            bm = O.verify_batch(spk, smsg, ssig, dst, nthreads=threads)
-            cdt = time.perf_counter() - t1
-            assert bm == synth.bitmap_of(sexp)
-            out["cpu_baseline"] = {"value": round(sample / cdt, 1), "unit": "verifies/s", "cores": threads, "kind": "port",
-                                   "sample": "first %d tuples of the same synthetic workload, C oracle (Montgomery 4x64, "
-                                             "oracle/bn254_oracle.c) on %d host threads, %.1f s wall" % (sample, threads, cdt)}
-            # second figure of SURVEY.md 8d: the same workload priced in the reference's own arithmetic (canonical
-            # operands, wide product, bit-serial const_rem_wide, fp.rs:404-407).  An estimate: the measured rate scaled
-            # by the measured cost ratio of the two field multiplies (additions ignored), not a timed verify.
-            ns_ref, ns_mont = O.bench_fp_mul(True, 100000), O.bench_fp_mul(False, 4000000)
-            out["cpu_baseline"]["reference_style_estimate"] = {
-                "value": round(sample / cdt * ns_mont / ns_ref, 2), "unit": "verifies/s", "cores": threads,
-                "fp_mul_ns": {"reference_style": round(ns_ref, 1), "montgomery": round(ns_mont, 1)}}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(O, synth, dst)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_baseline(O, synth, dst):
+    """The CPU oracle (kind "port") timed on this box's host cores on a bounded sample of the same workload shape."""
+    threads = min(os.cpu_count() or 1, 16)
+    sample = 512 * threads          # ~20 CPU-seconds of oracle work (~1.2 s wall on 16 threads)
+    spk, smsg, ssig, sexp = synth.make_batch(O, sample, dst, invalid_every=INVALID_EVERY, uniq=UNIQ)
+    t1 = time.perf_counter()
+    bm = O.verify_batch(spk, smsg, ssig, dst, nthreads=threads)
+    cdt = time.perf_counter() - t1
+    assert bm == synth.bitmap_of(sexp)
+    res = {"value": round(sample / cdt, 1), "unit": "verifies/s", "cores": threads, "kind": "port",
+           "sample": "%d tuples of the same workload shape (32-byte messages, 1/64 invalid), built from %d distinct "
+                     "oracle-signed tuples over an 8-key pool and tiled (CPU signing is the slow part); C oracle, Montgomery "
+                     "4x64 (oracle/bn254_oracle.c), %d host threads, %.1f s wall" % (sample, UNIQ, threads, cdt)}
+    # second figure of SURVEY.md 8d: whole verifies TIMED in the reference's own arithmetic (canonical operands, wide
+    # product, bit-serial const_rem_wide, schoolbook Fp2: fp.rs:404-407, fp2.rs:377-390) on a small sample
+    if hasattr(O, "verify_batch_refstyle"):
+        rs_n = 4 * threads
+        t2 = time.perf_counter()
+        bm2 = O.verify_batch_refstyle(spk[:128 * rs_n], smsg[:rs_n], ssig[:64 * rs_n], dst, nthreads=threads)
+        rdt = time.perf_counter() - t2
+        assert bm2 == synth.bitmap_of(sexp[:rs_n])
+        res["reference_style"] = {"value": round(rs_n / rdt, 3), "unit": "verifies/s", "cores": threads, "kind": "port",
+                                  "sample": "%d whole verifies (%d per thread) timed with every Fp multiplication done the reference's way: "
+                                            "canonical 4x64 operands, 512-bit product, 259-round bit-serial reduction (crypto-bigint 0.5.5 "
+                                            "const_rem_wide, fp.rs:404-407); same bitmap as the Montgomery run, %.1f s wall" % (rs_n, 4, rdt)}
+    return res
 
 
 if __name__ == "__main__":

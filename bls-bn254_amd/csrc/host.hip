@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -144,28 +145,58 @@ int blsbn254_profile_read(blsbn254_ctx* c, char* names, uint64_t* launches, doub
   return k;
 }
 
-// Measured v_mad_u64_u32 issue rate of the whole chip (lane-MADs per second), 4 waves per SIMD.
-int blsbn254_valu_peak(blsbn254_ctx* c, double* mads_per_s) {
-  if (!c || !mads_per_s) return BLSBN254_E_ARG;
+// VALU roofline probe (k_valu_peak, k_misc.hip), 4 waves per SIMD on every CU:
+//   out[0] v_mad_u64_u32 lane-MADs per second          out[1] plain VOP2 (v_add_u32 / v_xor_b32) lane-ops per second
+//   out[2] shader clock held under the MAD probe (Hz)  out[3] shader clock held under the VOP2 probe (Hz)
+//   out[4] compute units                               out[5] 4-cycle issue ceiling = CUs x 4 SIMDs x 16 lanes x out[2]
+// The clock is delta(s_memtime) / delta(s_memrealtime) x 100 MHz, median over all waves (MI355X_MICROARCH.md, DVFS item 6).
+struct EventPair {
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ~EventPair() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); }
+};
+int blsbn254_valu_probe(blsbn254_ctx* c, double out[6]) {
+  if (!c || !out) return BLSBN254_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));
   hipDeviceProp_t prop;
   HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
-  int blocks = prop.multiProcessorCount * 4, iters = 1 << 16;
-  HIPCHK(c, c->misc.reserve((size_t)blocks * 256 * 4 + 64));
-  hipEvent_t e0, e1;
-  HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
-  double best = 0;
-  for (int rep = 0; rep < 4; ++rep) {
-    HIPCHK(c, hipEventRecord(e0, c->stream));
-    hipLaunchKernelGGL(k_valu_peak, dim3(blocks), dim3(256), 0, c->stream, (uint32_t*)c->misc.p, 1u + rep, iters);
-    HIPCHK(c, hipEventRecord(e1, c->stream));
-    HIPCHK(c, hipEventSynchronize(e1));
-    float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
-    double rate = (double)blocks * 256 * iters * 8 / (ms * 1e-3);
-    if (rep > 0 && rate > best) best = rate;           // rep 0 warms the clocks
+  const int blocks = prop.multiProcessorCount * 4, iters = 1 << 16;
+  const size_t nwaves = (size_t)blocks * 4;
+  HIPCHK(c, c->misc.reserve((size_t)blocks * 256 * 4 + 64 + nwaves * 16));
+  uint64_t* d_stamps = (uint64_t*)((char*)c->misc.p + (((size_t)blocks * 256 * 4 + 63) & ~(size_t)63));
+  EventPair ev;                                   // destroyed on every return path
+  HIPCHK(c, hipEventCreate(&ev.e0)); HIPCHK(c, hipEventCreate(&ev.e1));
+  std::vector<uint64_t> st(nwaves * 2);
+  std::vector<double> clk(nwaves);
+  for (int kind = 0; kind < 2; ++kind) {
+    double best = 0, best_clk = 0;
+    for (int rep = 0; rep < 4; ++rep) {
+      HIPCHK(c, hipEventRecord(ev.e0, c->stream));
+      hipLaunchKernelGGL(k_valu_peak, dim3(blocks), dim3(256), 0, c->stream, (uint32_t*)c->misc.p, 1u + rep, iters, kind, d_stamps);
+      HIPCHK(c, hipEventRecord(ev.e1, c->stream));
+      HIPCHK(c, hipEventSynchronize(ev.e1));
+      float ms = 0; HIPCHK(c, hipEventElapsedTime(&ms, ev.e0, ev.e1));
+      double rate = (double)blocks * 256 * iters * 8 / (ms * 1e-3);
+      if (rep > 0 && rate > best) {                    // rep 0 warms the clocks
+        best = rate;
+        HIPCHK(c, hipMemcpy(st.data(), d_stamps, nwaves * 16, hipMemcpyDeviceToHost));
+        for (size_t w = 0; w < nwaves; ++w) clk[w] = st[2 * w + 1] ? (double)st[2 * w] / (double)st[2 * w + 1] * 100e6 : 0;
+        std::nth_element(clk.begin(), clk.begin() + nwaves / 2, clk.end());
+        best_clk = clk[nwaves / 2];
+      }
+    }
+    out[kind] = best; out[2 + kind] = best_clk;
   }
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  *mads_per_s = best;
+  out[4] = prop.multiProcessorCount;
+  out[5] = (double)prop.multiProcessorCount * 64.0 * out[2] / 4.0;
+  return 0;
+}
+// Measured v_mad_u64_u32 issue rate of the whole chip (lane-MADs per second): out[0] of the probe above.
+int blsbn254_valu_peak(blsbn254_ctx* c, double* mads_per_s) {
+  if (!c || !mads_per_s) return BLSBN254_E_ARG;
+  double o[6];
+  int rc = blsbn254_valu_probe(c, o);
+  if (rc) return rc;
+  *mads_per_s = o[0];
   return 0;
 }
 

@@ -107,23 +107,50 @@ BN_KERNEL k_g2_codec(const uint8_t* in, size_t n, uint8_t* out, uint8_t* status,
   status[i] = ok ? 1 : 0;
 }
 // VALU roofline probe: 8 independent 64-bit multiply-accumulate chains per lane (compiler-selected
-// v_mad_u64_u32, no shared VCC), every CU busy at 4 waves per SIMD.  The denominator of bench.py's
-// roofline.frac is measured in the same run (BASELINE.md section 3 "same-run rule").
-__global__ void __launch_bounds__(256) k_valu_peak(uint32_t* out, uint32_t seed, int iters) {
+// v_mad_u64_u32, each with its own carry-out SGPR pair, no shared VCC), every CU busy at 4 waves per SIMD.  The
+// denominator of bench.py's roofline.frac is measured in the same run (BASELINE.md section 3 "same-run rule").
+// kind 1 runs the same shape with plain 32-bit VOP2 work (v_add_u32 / v_xor_b32) instead: the full-rate issue ceiling.
+// Lane 0 of every wave stamps the shader-cycle counter and the 100 MHz constant clock around the loop into
+// `stamps` (4 x u64 per wave; a buffer nothing else reads): their ratio is the clock the chip holds under this load.
+__global__ void __launch_bounds__(256) k_valu_peak(uint32_t* out, uint32_t seed, int iters, int kind, uint64_t* stamps) {
   uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   uint32_t a = seed * 2654435761u + tid, b = (seed ^ 0x9e3779b9u) + tid * 7u;
-  uint64_t acc[8];
-  for (int c = 0; c < 8; ++c) acc[c] = tid + c;
-  for (int i = 0; i < iters; ++i) {
+  uint64_t c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  uint32_t res;
+  if (kind == 0) {
+    uint64_t acc[8];
+    for (int c = 0; c < 8; ++c) acc[c] = tid + c;
+    for (int i = 0; i < iters; ++i) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      acc[c] = (uint64_t)a * (uint32_t)(b + c) + acc[c];
-      asm("" : "+v"(acc[c]));
+      for (int c = 0; c < 8; ++c) {
+        acc[c] = (uint64_t)a * (uint32_t)(b + c) + acc[c];
+        asm("" : "+v"(acc[c]));
+      }
     }
+    uint64_t s = 0;
+    for (int c = 0; c < 8; ++c) s ^= acc[c];
+    res = (uint32_t)s ^ (uint32_t)(s >> 32);
+  } else {
+    uint32_t acc[8];
+    for (int c = 0; c < 8; ++c) acc[c] = tid + c;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        uint32_t v = acc[c];
+        v = (c & 1) ? (v ^ b) : v + a;                  // exactly one VOP2 instruction per chain step
+        asm("" : "+v"(v));
+        acc[c] = v;
+      }
+    }
+    res = 0;
+    for (int c = 0; c < 8; ++c) res ^= acc[c];
   }
-  uint64_t s = 0;
-  for (int c = 0; c < 8; ++c) s ^= acc[c];
-  out[tid] = (uint32_t)s ^ (uint32_t)(s >> 32);
+  uint64_t c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  out[tid] = res;
+  if (stamps && (threadIdx.x & 63) == 0) {
+    uint64_t* w = stamps + 2 * (size_t)(tid >> 6);
+    w[0] = c1 - c0; w[1] = r1 - r0;
+  }
 }
 // status reductions
 __global__ void k_status_reduce(const uint8_t* status, size_t n, uint8_t want_mask, uint8_t want_val, int* first_bad) {

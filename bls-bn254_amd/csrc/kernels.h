@@ -47,6 +47,6 @@ BN_KERNEL k_g1p_to_bytes(const int32_t* ws, size_t stride, size_t m, uint8_t* ou
 BN_KERNEL k_rlc_gather(const uint32_t* idx, size_t m, const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n,
                        const uint8_t* sub_ok, uint8_t* c_pks, uint8_t* c_sigs, int32_t* c_h, uint8_t* c_sub);
 BN_KERNEL k_lagrange(const uint8_t* ids, size_t t, uint8_t* scalars, uint8_t* status);
-__global__ void __launch_bounds__(256) k_valu_peak(uint32_t* out, uint32_t seed, int iters);
+__global__ void __launch_bounds__(256) k_valu_peak(uint32_t* out, uint32_t seed, int iters, int kind, uint64_t* stamps);
 __global__ void k_status_reduce(const uint8_t* status, size_t n, uint8_t want_mask, uint8_t want_val, int* first_bad);
 __global__ void k_and_reduce(const uint8_t* flags, const uint8_t* sub_ok, size_t n, int* all_ok);

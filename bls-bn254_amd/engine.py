@@ -318,6 +318,14 @@ class Engine:
         self._chk(self._lib.blsbn254_valu_peak(self._ctx, ctypes.byref(v)))
         return v.value
 
+    def valu_probe(self):
+        """The whole VALU probe (blsbn254_valu_probe): MAD and plain-VOP2 rates, the clock held under each probe
+        kernel, and the 4-cycle issue ceiling at that clock."""
+        o = (ctypes.c_double * 6)()
+        self._chk(self._lib.blsbn254_valu_probe(self._ctx, o))
+        return {"mad_per_s": o[0], "vop2_per_s": o[1], "clock_hz_mad": o[2], "clock_hz_vop2": o[3], "cus": int(o[4]),
+                "issue_ceiling_per_s": o[5]}
+
     def profile_read(self):
         names = ctypes.create_string_buffer(32 * 64)
         launches = (ctypes.c_uint64 * 64)()

@@ -36,10 +36,16 @@ def allreduce_bitmap(local_bm, lo, m, n, dist, torch, group=None):
     """local_bm: uint8 tensor, LSB-first bitmap of this rank's m tuples (global indices lo..lo+m).
     Returns the full-batch bitmap as an int32 word tensor, identical on every rank."""
     nwords = (n + 31) // 32
-    bits = torch.zeros(nwords * 32, dtype=torch.uint8, device=local_bm.device)
-    if m:
-        bits[lo:lo + m] = bitmap_bytes_to_bits(local_bm, m, torch)
-    words = bits_to_words(bits, torch)
+    if lo % 32 == 0 and m % 32 == 0 and local_bm.numel() * 8 >= m:
+        # word-aligned shard (every power-of-two batch): the local bytes ARE the shard's words
+        words = torch.zeros(nwords, dtype=torch.int32, device=local_bm.device)
+        if m:
+            words[lo // 32:(lo + m) // 32] = local_bm[:m // 8].view(torch.int32)
+    else:
+        bits = torch.zeros(nwords * 32, dtype=torch.uint8, device=local_bm.device)
+        if m:
+            bits[lo:lo + m] = bitmap_bytes_to_bits(local_bm, m, torch)
+        words = bits_to_words(bits, torch)
     if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(words, op=dist.ReduceOp.SUM, group=group)
     return words
@@ -47,11 +53,10 @@ def allreduce_bitmap(local_bm, lo, m, n, dist, torch, group=None):
 
 def verify_batch_sharded(verify_local, n, rank, world, dist, torch, device, group=None):
     """verify_local(lo, hi) -> uint8 bitmap tensor (on `device`) for global tuples lo..hi.
-    Returns (full bitmap int32 words on `device`, all_valid flag)."""
+    Returns the full bitmap as int32 words on `device`, identical on every rank."""
     lo, hi = shard_range(n, rank, world)
     local = verify_local(lo, hi) if hi > lo else torch.zeros(0, dtype=torch.uint8, device=device)
-    words = allreduce_bitmap(local, lo, hi - lo, n, dist, torch, group)
-    return words
+    return allreduce_bitmap(local, lo, hi - lo, n, dist, torch, group)
 
 
 def aggregate_verify_sharded(partial_local, finish, n, rank, world, dist, torch, device, group=None):

@@ -176,6 +176,10 @@ int blsbn254_profile_read(blsbn254_ctx* ctx, char* names /* max_entries*32 */, u
 
 /* Measured whole-chip v_mad_u64_u32 issue rate (lane-MADs per second): the VALU roofline denominator. */
 int blsbn254_valu_peak(blsbn254_ctx* ctx, double* mads_per_s);
+/* The whole probe: out[0] v_mad_u64_u32 lane-MADs/s, out[1] plain 32-bit VOP2 lane-ops/s, out[2] / out[3] the shader
+ * clock (Hz) the chip held under each of the two probe kernels (in-kernel s_memtime / s_memrealtime), out[4] compute
+ * units, out[5] the 4-cycle single-wave issue ceiling at that clock = CUs x 4 SIMDs x 16 lanes x out[2]. */
+int blsbn254_valu_probe(blsbn254_ctx* ctx, double out[6]);
 
 #ifdef __cplusplus
 }

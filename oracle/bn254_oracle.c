@@ -39,7 +39,11 @@ void oracle_counters_reset(void) { cnt_mul = cnt_sqr = 0; }
 void oracle_counters_get(u64* m, u64* s) { *m = cnt_mul; *s = cnt_sqr; }
 
 /* ------------------------------------------------------------------ 256-bit Montgomery arithmetic */
-typedef struct { u64 m[4]; u64 ninv; u64 r1[4]; u64 r2[4]; } modctx;
+/* refstyle != 0: "reference-style" arithmetic for the CPU baseline's second figure (SURVEY.md 8d variant (i)) -- elements are
+ * kept in CANONICAL form (the Montgomery radix degenerates to R = 1: r1 = r2 = 1) and every product goes through
+ * refstyle_mul below (wide product + bit-serial reduction, fp.rs:404-407).  p256 = the field form of 2^256. */
+typedef struct { u64 m[4]; u64 ninv; u64 r1[4]; u64 r2[4]; u64 p256[4]; int refstyle; } modctx;
+static void refstyle_mul(u64 r[4], const u64 a[4], const u64 b[4], const u64 m[4], int mbits);
 
 static int ge256(const u64 a[4], const u64 b[4]) {
   for (int i = 3; i >= 0; --i) { if (a[i] != b[i]) return a[i] > b[i]; }
@@ -63,6 +67,7 @@ static void mod_sub(u64 r[4], const u64 a[4], const u64 b[4], const modctx* M) {
   if (sub256(r, a, b)) add256(r, r, M->m);
 }
 static void mont_mul(u64 r[4], const u64 a[4], const u64 b[4], const modctx* M) {
+  if (M->refstyle) { refstyle_mul(r, a, b, M->m, 254); return; }
   u64 t[6] = {0, 0, 0, 0, 0, 0};
   for (int i = 0; i < 4; ++i) {
     u128 c = 0;
@@ -86,6 +91,18 @@ static void modctx_init(modctx* M, const u64 m[4]) {
     if (i == 255) memcpy(M->r1, x, 32);
   }
   memcpy(M->r2, x, 32);
+  memcpy(M->p256, M->r2, 32);                    /* Montgomery form of 2^256 = R * R mod m */
+  M->refstyle = 0;
+}
+static void modctx_set_refstyle(modctx* M, int on) {
+  u64 keep[4]; memcpy(keep, M->m, 32);
+  modctx_init(M, keep);
+  if (on) {
+    static const u64 one[4] = {1, 0, 0, 0};
+    memcpy(M->p256, M->r1, 32);                  /* canonical 2^256 mod m */
+    memcpy(M->r1, one, 32); memcpy(M->r2, one, 32);
+    M->refstyle = 1;
+  }
 }
 static void be32_to_limbs(u64 l[4], const uint8_t b[32]) {
   for (int i = 0; i < 4; ++i) {
@@ -140,7 +157,7 @@ static int fp_sgn0(fp a) { u64 t[4]; fp_canon(t, a); return (int)(t[0] & 1); }
 static fp fp_from_okm(const uint8_t okm[48]) {
   uint8_t hi[32]; memset(hi, 0, 16); memcpy(hi + 16, okm, 16);
   u64 h[4], l[4]; be32_to_limbs(h, hi); be32_to_limbs(l, okm + 16);
-  fp H, L; mont_mul(H.l, h, FP.r2, &FP); mont_mul(H.l, H.l, FP.r2, &FP);   /* hi * 2^256 */
+  fp H, L; mont_mul(H.l, h, FP.r2, &FP); mont_mul(H.l, H.l, FP.p256, &FP);   /* hi * 2^256 */
   mont_mul(L.l, l, FP.r2, &FP);
   return fp_add(H, L);
 }
@@ -156,6 +173,10 @@ static inline fp2 f2_conj(fp2 a) { fp2 r = {a.c0, fp_neg(a.c1)}; return r; }
 static inline int f2_eq(fp2 a, fp2 b) { return fp_eq(a.c0, b.c0) && fp_eq(a.c1, b.c1); }
 static inline int f2_is_zero(fp2 a) { return fp_is_zero(a.c0) && fp_is_zero(a.c1); }
 static fp2 f2_mul(fp2 a, fp2 b) {                 /* Karatsuba; same value as fp2.rs:377-390 */
+  if (FP.refstyle) {                              /* the reference's own schoolbook form, four products (fp2.rs:377-390) */
+    fp2 s = {fp_sub(fp_mul(a.c0, b.c0), fp_mul(a.c1, b.c1)), fp_add(fp_mul(a.c0, b.c1), fp_mul(a.c1, b.c0))};
+    return s;
+  }
   fp t0 = fp_mul(a.c0, b.c0), t1 = fp_mul(a.c1, b.c1);
   fp t2 = fp_mul(fp_add(a.c0, a.c1), fp_add(b.c0, b.c1));
   fp2 r = {fp_sub(t0, t1), fp_sub(fp_sub(t2, t0), t1)};
@@ -834,8 +855,14 @@ static void div_small(u64 q[4], const u64 a[4], u64 d) {
   for (int i = 3; i >= 0; --i) { u128 cur = (rem << 64) | a[i]; q[i] = (u64)(cur / d); rem = cur % d; }
 }
 static pthread_once_t once = PTHREAD_ONCE_INIT;
+static void init_constants(void);
 static void init_impl(void) {
   modctx_init(&FP, P_LIMBS); modctx_init(&FR, R_LIMBS);
+  init_constants();
+}
+/* every field constant is derived from FP.r1 / fp_from_u64 / fp_from_be, so re-running this after switching FP's
+ * mode (modctx_set_refstyle) re-creates them in the other representation */
+static void init_constants(void) {
   memset(&FP_ZERO, 0, sizeof FP_ZERO); memcpy(FP_ONE.l, FP.r1, 32);
   F2_ZERO.c0 = F2_ZERO.c1 = FP_ZERO; F2_ONE.c0 = FP_ONE; F2_ONE.c1 = FP_ZERO;
   F6_ZERO.c0 = F6_ZERO.c1 = F6_ZERO.c2 = F2_ZERO; F6_ONE = F6_ZERO; F6_ONE.c0 = F2_ONE;
@@ -1021,6 +1048,17 @@ int oracle_verify_batch_mt(const uint8_t* pks, const uint8_t* msgs, const uint64
   for (size_t i = 0; i < n; ++i) set_bit(bm, i, res[i]);
   free(res);
   return 0;
+}
+/* The same batch verification with every Fp product done the reference's way (canonical operands, wide product,
+ * bit-serial const_rem_wide; schoolbook Fp2): the timed "reference-style" CPU baseline.  Switches the global field
+ * context for the duration of the call -- NOT re-entrant: no other oracle call may run concurrently. */
+int oracle_verify_batch_refstyle_mt(const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, size_t n,
+                                    const uint8_t* dst, size_t dst_len, uint8_t* bm, int nthreads) {
+  init();
+  modctx_set_refstyle(&FP, 1); init_constants();
+  int rc = oracle_verify_batch_mt(pks, msgs, off, sigs, n, dst, dst_len, bm, nthreads);
+  modctx_set_refstyle(&FP, 0); init_constants();
+  return rc;
 }
 /* CoreAggregateVerify: prod e(H(m_i), pk_i) * e(sig, -G2gen) == 1; n == 0 -> invalid */
 int oracle_aggregate_verify(const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t agg_sig[64],

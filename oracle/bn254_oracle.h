@@ -47,6 +47,9 @@ int oracle_verify_batch(const uint8_t* pks, const uint8_t* msgs, const uint64_t*
                         size_t n, const uint8_t* dst, size_t dst_len, uint8_t* valid_bitmap);
 int oracle_verify_batch_mt(const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs,
                            size_t n, const uint8_t* dst, size_t dst_len, uint8_t* valid_bitmap, int nthreads);
+/* same bitmap, every Fp product in the reference's own arithmetic (timed baseline only; not re-entrant) */
+int oracle_verify_batch_refstyle_mt(const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs,
+                           size_t n, const uint8_t* dst, size_t dst_len, uint8_t* valid_bitmap, int nthreads);
 int oracle_aggregate_verify(const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
                             const uint8_t agg_sig[64], const uint8_t* dst, size_t dst_len, int* valid);
 int oracle_aggregate_sigs(const uint8_t* sigs, size_t n, uint8_t out[64]);

@@ -229,6 +229,17 @@ def counters_get():
     return a.value, b.value
 
 
+def verify_batch_refstyle(pks, msgs, sigs, dst, nthreads=1):
+    """verify_batch with every Fp product done in the reference's own arithmetic (fp.rs:404-407, fp2.rs:377-390):
+    ~100x slower, same bitmap.  Timed CPU baseline only."""
+    n = len(msgs)
+    data, off = pack_msgs(msgs)
+    a, pa = _buf(pks); m, pm = _buf(data); s, ps = _buf(sigs); d, pd = _buf(dst); o, po = _out((n + 7) // 8)
+    _chk(lib().oracle_verify_batch_refstyle_mt(pa, pm, off.ctypes.data_as(u64p), ps, ctypes.c_size_t(n), pd,
+                                               ctypes.c_size_t(len(dst)), po, ctypes.c_int(max(1, nthreads))))
+    return o[:(n + 7) // 8].tobytes()
+
+
 def verify_core_counts():
     """Exact Fp mul+sqr counts of the algorithmic unit: (variable-Q Miller pair, fixed-Q pair from table, final exp, table entries)."""
     a = (ctypes.c_uint64 * 4)()

@@ -51,42 +51,57 @@ def make_batch(oracle, n, dst, pool=8, invalid_every=0, uniq=None):
     return b"".join(pks), msgs, b"".join(sigs), exp
 
 
-def make_batch_gpu(engine, oracle, n, dst, pool=1024, invalid_every=0, spot=1000, seed=1):
-    """n UNIQUE signed tuples: key pool of `pool` keys, 32-byte messages msg_i, signatures
-    sig_i = [sk_(i mod pool)] H(msg_i) made by the engine's own GPU signing kernels and spot-checked at `spot`
-    random indices against the CPU oracle.  Corruption pattern as in make_batch."""
+def make_batch_gpu(engine, oracle, n, dst, pool=1024, invalid_every=0, spot=1000, seed=1, base=0):
+    """n UNIQUE signed tuples: key pool of `pool` keys, 32-byte messages msg_g, signatures
+    sig_g = [sk_(g mod pool)] H(msg_g) made by the engine's own GPU signing kernels and spot-checked at `spot`
+    random indices against the CPU oracle.  g = base + i is the tuple's GLOBAL index (rank r of a sharded run
+    passes base = r * n, so every rank holds different messages); corruption pattern as in make_batch, keyed on g."""
     import random
-    pool = min(pool, n)
+    pool = min(pool, max(n, 1))
     sks = [sk_of(k) for k in range(pool)]
     skb = b"".join(s.to_bytes(32, "big") for s in sks)
     pk_pool = engine.sk_to_pk_batch(skb, pool)
-    msgs = [msg_of(i) for i in range(n)]
-    sk_all = skb * (n // pool) + skb[:32 * (n % pool)]
+    msgs = [msg_of(base + i) for i in range(n)]
+    rot = base % pool                                   # tuple i uses key (base + i) mod pool
+    skr = skb[32 * rot:] + skb[:32 * rot]
+    pkr = pk_pool[128 * rot:] + pk_pool[:128 * rot]
+    sk_all = skr * (n // pool) + skr[:32 * (n % pool)]
     sigs = bytearray(engine.sign_batch(sk_all, msgs, dst))
-    pks = bytearray(pk_pool * (n // pool) + pk_pool[:128 * (n % pool)])
-    rnd = random.Random(seed)
+    pks = bytearray(pkr * (n // pool) + pkr[:128 * (n % pool)])
+    rnd = random.Random(seed + base)
     for i in ([0, n - 1] + [rnd.randrange(n) for _ in range(spot)])[:spot + 2]:
-        assert bytes(sigs[64 * i:64 * i + 64]) == oracle.sign(sks[i % pool], msgs[i], dst), "GPU signature differs from the oracle at %d" % i
+        k = (base + i) % pool
+        assert bytes(sigs[64 * i:64 * i + 64]) == oracle.sign(sks[k], msgs[i], dst), "GPU signature differs from the oracle at %d" % i
         if i < pool or i % 97 == 0:
-            assert bytes(pks[128 * i:128 * i + 128]) == oracle.sk_to_pk(sks[i % pool])
+            assert bytes(pks[128 * i:128 * i + 128]) == oracle.sk_to_pk(sks[k])
     exp = [True] * n
     if invalid_every:
         g1 = oracle.g1_generator()
-        for i in range(invalid_every - 1, n, invalid_every):
-            kind = (i // invalid_every) % 5
+        first = (invalid_every - 1 - base) % invalid_every
+        for i in range(first, n, invalid_every):
+            g = base + i
+            kind = (g // invalid_every) % 5
             exp[i] = False
             if kind == 0:
                 msgs[i] = bytes([msgs[i][0] ^ 1]) + msgs[i][1:]
             elif kind == 1:
                 sigs[64 * i:64 * i + 64] = oracle.g1_add(bytes(sigs[64 * i:64 * i + 64]), g1)
             elif kind == 2:
-                j = (i + 1) % pool
+                j = (g + 1) % pool
                 pks[128 * i:128 * i + 128] = pk_pool[128 * j:128 * j + 128]
             elif kind == 3:
                 sigs[64 * i + 63] ^= 1
             else:
                 pks[128 * i:128 * i + 128] = NON_SUBGROUP_PK
     return bytes(pks), msgs, bytes(sigs), exp
+
+
+def expected_bits(n_total, invalid_every):
+    """closed form of the validity pattern over global indices 0..n_total-1"""
+    a = np.ones(n_total, dtype=np.uint8)
+    if invalid_every:
+        a[invalid_every - 1::invalid_every] = 0
+    return a
 
 
 def bitmap_of(bools):

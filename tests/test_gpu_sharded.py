@@ -1,0 +1,122 @@
+"""GPU (MI355X): the N > 1 path with the REAL engine.  Two child processes share device 0 (the GPU box has one
+card), rendezvous over gloo on 127.0.0.1, and run bls-bn254_amd/sharded.py with Engine.verify_batch_dev /
+aggregate_partial / aggregate_finish as the per-shard workers; results are compared with the CPU oracle on the same
+inputs.  Also: `bench.py --gpus 2` started as a plain process must spawn its two ranks itself and report n_gpus 2."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _verify_worker(rank, world, port, n, outdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import blsbn254_loader
+    M = blsbn254_loader.load()
+    sharded = __import__("bls_bn254_amd.sharded", fromlist=["x"])
+    from oracle import oracle as O
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    eng = M.Engine(0)
+    dst = b"TEST_DST"
+    pks, msgs, sigs, exp = synth.make_batch(O, n, dst, invalid_every=3, uniq=12)       # same batch on both ranks
+
+    def verify_local(lo, hi):
+        data, off = M.engine.pack_messages(msgs[lo:hi])
+        m = hi - lo
+        t_pk = torch.frombuffer(bytearray(pks[128 * lo:128 * hi]), dtype=torch.uint8).to(dev)
+        t_sg = torch.frombuffer(bytearray(sigs[64 * lo:64 * hi]), dtype=torch.uint8).to(dev)
+        t_ms = torch.frombuffer(bytearray(data) or bytearray(1), dtype=torch.uint8).to(dev)
+        t_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+        t_bm = torch.zeros((m + 7) // 8, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        eng.verify_batch_dev(t_pk.data_ptr(), t_ms.data_ptr(), t_off.data_ptr(), t_sg.data_ptr(), m, t_bm.data_ptr(), dst)
+        eng.synchronize()
+        return t_bm.cpu()          # gloo reduces host tensors
+    words = sharded.verify_batch_sharded(verify_local, n, rank, world, dist, torch, torch.device("cpu"))
+    got = sharded.words_to_bitmap_bytes(words.numpy(), n)
+    np.save(os.path.join(outdir, "v%d.npy" % rank), np.frombuffer(got, dtype=np.uint8))
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+def _agg_worker(rank, world, port, n, outdir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import blsbn254_loader
+    M = blsbn254_loader.load()
+    sharded = __import__("bls_bn254_amd.sharded", fromlist=["x"])
+    from oracle import oracle as O
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    eng = M.Engine(0)
+    dst = b"TEST_DST"
+    sks = [synth.sk_of(k) for k in range(n)]
+    pks = [O.sk_to_pk(s) for s in sks]
+    msgs = [synth.msg_of(i) for i in range(n)]
+    agg = O.aggregate_sigs(b"".join(O.sign(s, m, dst) for s, m in zip(sks, msgs)), n)
+
+    def partial_local(lo, hi):
+        return eng.aggregate_partial(b"".join(pks[lo:hi]), msgs[lo:hi], dst)
+
+    def finish(partials, k):
+        return eng.aggregate_finish(partials, k, agg)
+    res = [sharded.aggregate_verify_sharded(partial_local, finish, n, rank, world, dist, torch, torch.device("cpu"))]
+    msgs[n - 1] = b"tampered"                       # lives in the last rank's shard
+    res.append(sharded.aggregate_verify_sharded(partial_local, finish, n, rank, world, dist, torch, torch.device("cpu")))
+    np.save(os.path.join(outdir, "a%d.npy" % rank), np.array(res, dtype=np.uint8))
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [37, 256])
+def test_world2_verify_batch_sharded_with_engine(tmp_path, oracle, n):
+    import torch.multiprocessing as mp
+    mp.spawn(_verify_worker, args=(2, _free_port(), n, str(tmp_path)), nprocs=2, join=True)
+    pks, msgs, sigs, exp = synth.make_batch(oracle, n, b"TEST_DST", invalid_every=3, uniq=12)
+    want = oracle.verify_batch(pks, msgs, sigs, b"TEST_DST", nthreads=4)
+    assert want == synth.bitmap_of(exp)
+    for r in range(2):
+        assert np.load(tmp_path / ("v%d.npy" % r)).tobytes() == want
+
+
+def test_world2_aggregate_verify_sharded_with_engine(tmp_path, oracle):
+    import torch.multiprocessing as mp
+    mp.spawn(_agg_worker, args=(2, _free_port(), 9, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert np.load(tmp_path / ("a%d.npy" % r)).tolist() == [1, 0]
+
+
+def test_bench_spawns_its_own_ranks():
+    """plain `python bench.py --gpus 2` (WORLD_SIZE unset): the parent starts two ranks before touching the GPU and relays
+    rank 0's line; both ranks rehearse on device 0 over gloo (the real run is one rank per GPU over RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--backend", "gloo", "--all-on-device0", "--tuples-per-gpu", "8192"],
+                         env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["tuples_total"] == 2 * 8192 and j["value"] > 0
+    assert "cpu_baseline" not in j                       # rank 0 at N = 1 only
+
+
