@@ -4,11 +4,11 @@ The directory name carries a hyphen (it mirrors the reference repository's name)
 through `blsbn254_loader.load()` at the repo root, which registers it as the module `bls_bn254_amd`.
 
 Layout:
-  csrc/        HIP kernels + C-ABI host code (kernels.hip), device arithmetic headers
+  csrc/        HIP kernels (k_*.hip) + C-ABI host code (host.hip, multi.hip), device arithmetic headers
   tools/       constant generator (bn254_consts.h)
   build.py     hipcc driver (builds libblsbn254_hip.so in-tree)
   engine.py    ctypes binding of include/blsbn254.h with the reference's operator names
   sharded.py   one-process-per-GPU sharding over torch.distributed (RCCL)
 """
-from .engine import (Bn254Error, Engine, InvalidG1Bytes, InvalidG2Bytes, InvalidGtBytes,  # noqa: F401
+from .engine import (Bn254Error, Engine, MultiEngine, InvalidG1Bytes, InvalidG2Bytes, InvalidGtBytes,  # noqa: F401
                      InvalidScalarBytes, DEFAULT_DST, POP_DST, library_path, load_library)

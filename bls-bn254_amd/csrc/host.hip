@@ -1,6 +1,7 @@
 // host.hip -- C-ABI host side (include/blsbn254.h): contexts, workspace, staging, kernel launches.
 // There is no CPU fallback in this file: every entry point launches kernels or fails.
 #include <hip/hip_runtime.h>
+#include <sys/random.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -40,6 +41,8 @@ struct blsbn254_ctx {
   DevBuf rlc_a2, rlc_a, rlc_b, rlc_elig, rlc_f2, rlc_bytes, rlc_neg, rlc_ok, rlc_idx, rlc_cpk, rlc_csig, rlc_ch, rlc_csub, rlc_cbm;   // RLC batch verification
   DevBuf status_all;     // per-element decode status of a chunked call, all chunks
   DevBuf fe_slots;       // the ten named powers of the t -> t^x addition chain, 10 x 108 x n limbs
+  uint8_t dst_host[256];  // the (pre-hashed if oversize) DST currently resident in `dst`, and its length; -1 = none
+  int dst_host_len = -1;
   size_t chunk = (size_t)1 << 22;   // tuples per launch of the chunked entry points (BLSBN254_CHUNK_LANES overrides: tests)
   bool profiling = false;
   std::map<std::string, ProfEntry> prof;
@@ -84,6 +87,7 @@ const char* blsbn254_strerror(int code) {
     case BLSBN254_E_HIP: return "HIP runtime error";
     case BLSBN254_E_NOMEM: return "out of device memory";
     case BLSBN254_E_NO_DEVICE: return "no gfx950 device available (there is no CPU fallback)";
+    case BLSBN254_E_RCCL: return "RCCL error";
     default: return "unknown error";
   }
 }
@@ -148,7 +152,9 @@ int blsbn254_profile_read(blsbn254_ctx* c, char* names, uint64_t* launches, doub
 // VALU roofline probe (k_valu_peak, k_misc.hip), 4 waves per SIMD on every CU:
 //   out[0] v_mad_u64_u32 lane-MADs per second          out[1] plain VOP2 (v_add_u32 / v_xor_b32) lane-ops per second
 //   out[2] shader clock held under the MAD probe (Hz)  out[3] shader clock held under the VOP2 probe (Hz)
-//   out[4] compute units                               out[5] 4-cycle issue ceiling = CUs x 4 SIMDs x 16 lanes x out[2]
+//   out[4] compute units                               out[5] 4-cycle issue ceiling = CUs x 4 SIMDs x 16 lane-ops/cycle x out[2]
+//   (what ONE wave per SIMD can issue: a wave64 VALU instruction every 4 cycles; with several waves per SIMD plain VOP2
+//   work issues faster than that -- out[1] -- while v_mad_u64_u32 does not -- out[0])
 // The clock is delta(s_memtime) / delta(s_memrealtime) x 100 MHz, median over all waves (MI355X_MICROARCH.md, DVFS item 6).
 struct EventPair {
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -187,7 +193,7 @@ int blsbn254_valu_probe(blsbn254_ctx* c, double out[6]) {
     out[kind] = best; out[2 + kind] = best_clk;
   }
   out[4] = prop.multiProcessorCount;
-  out[5] = (double)prop.multiProcessorCount * 64.0 * out[2] / 4.0;
+  out[5] = (double)prop.multiProcessorCount * 4.0 * 16.0 * out[2];   // one wave64 instruction per 4 cycles per SIMD = 16 lane-ops per cycle per SIMD
   return 0;
 }
 // Measured v_mad_u64_u32 issue rate of the whole chip (lane-MADs per second): out[0] of the probe above.
@@ -208,10 +214,17 @@ static int stage_dst(blsbn254_ctx* c, const uint8_t* dst, size_t dst_len, uint32
     sha256_update(s, (const uint8_t*)"H2C-OVERSIZE-DST-", 17); sha256_update(s, dst, dst_len); sha256_final(s, tmp);
     dst_len = 32;
   } else if (dst_len) std::memcpy(tmp, dst, dst_len);
-  HIPCHK(c, c->dst.reserve(256));
-  if (dst_len) HIPCHK(c, hipMemcpyAsync(c->dst.p, tmp, dst_len, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));     // tmp is on the stack
   *out_len = (uint32_t)dst_len;
+  // the same tag as the previous call (every step of a steady-state caller): already resident, nothing to copy or wait for
+  if (c->dst_host_len == (int)dst_len && (dst_len == 0 || std::memcmp(c->dst_host, tmp, dst_len) == 0)) return 0;
+  HIPCHK(c, c->dst.reserve(256));
+  c->dst_host_len = -1;
+  if (dst_len) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));           // kernels of an earlier call may still be reading the old tag
+    std::memcpy(c->dst_host, tmp, dst_len);                // ctx-owned source: outlives the asynchronous copy
+    HIPCHK(c, hipMemcpyAsync(c->dst.p, c->dst_host, dst_len, hipMemcpyHostToDevice, c->stream));
+  }
+  c->dst_host_len = (int)dst_len;
   return 0;
 }
 static int check_offsets(const uint64_t* off, size_t n) {
@@ -466,10 +479,19 @@ int blsbn254_verify_batch_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8
 static const size_t RLC_GROUP = 16;      // tuples per shared final exponentiation (power of two)
 int blsbn254_verify_batch_rlc(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs,
                               size_t n, const uint8_t* dst, size_t dst_len, const uint8_t seed[32], uint8_t* bm) {
-  if (!c || !off || !seed || (n && (!pks || !sigs || !bm)) || (dst_len && !dst)) return BLSBN254_E_ARG;
+  if (!c || !off || (n && (!pks || !sigs || !bm)) || (dst_len && !dst)) return BLSBN254_E_ARG;
   if (n == 0) return 0;
   CHECK_LANES(c, n);
-  if (n > ((size_t)1 << 26)) return BLSBN254_E_ARG;                 // one pass; split larger batches in the caller
+  uint8_t own_seed[32];
+  if (!seed) {                                        // the normal case: 32 bytes from the OS, drawn now -- after the batch is fixed
+    size_t got = 0;
+    while (got < sizeof own_seed) {
+      ssize_t k = getrandom(own_seed + got, sizeof own_seed - got, 0);
+      if (k <= 0) { c->last_error = "getrandom failed"; return BLSBN254_E_HIP; }
+      got += (size_t)k;
+    }
+    seed = own_seed;
+  }
   HIPCHK(c, hipSetDevice(c->device));
   uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
   if (rc) return rc;
@@ -703,6 +725,47 @@ int blsbn254_threshold_combine(blsbn254_ctx* c, const uint8_t* ids, const uint8_
   return g1_sum_to_bytes(c, t, out_sig);
 }
 
+// ---------------- field / tower primitives (debug ABI) and Gt group operations
+static size_t field_op_width(int op) { return op < 0 ? 0 : op <= 8 ? 32 : (op >= 16 && op <= 21) ? 64 : (op >= 32 && op <= 35) ? 192 : (op >= 48 && op <= 56) ? 384 : 0; }
+static bool field_op_binary(int op) { return op == 0 || op == 3 || op == 4 || op == 16 || op == 32 || op == 48 || op == 56; }
+int blsbn254_field_op_batch(blsbn254_ctx* c, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
+  const size_t w = field_op_width(op);
+  if (!c || w == 0 || (n && (!a || !out || (field_op_binary(op) && !b)))) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  const bool bin = field_op_binary(op);
+  HIPCHK(c, c->in_a.reserve(w * n)); HIPCHK(c, c->out.reserve(w * n)); HIPCHK(c, c->status.reserve(n));
+  if (bin) HIPCHK(c, c->in_b.reserve(w * n));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, a, w * n, hipMemcpyHostToDevice, c->stream));
+  if (bin) HIPCHK(c, hipMemcpyAsync(c->in_b.p, b, w * n, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "field_op", k_field_op, n, op, (const uint8_t*)c->in_a.p, bin ? (const uint8_t*)c->in_b.p : (const uint8_t*)nullptr, n,
+         (uint8_t*)c->out.p, (uint8_t*)c->status.p);
+  int bad; int rc = first_bad(c, (const uint8_t*)c->status.p, n, 1, 1, &bad);
+  if (rc) return rc;
+  if (bad >= 0) return BLSBN254_ERR_GT;
+  HIPCHK(c, hipMemcpyAsync(out, c->out.p, w * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int blsbn254_gt_mul_batch(blsbn254_ctx* c, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
+  return blsbn254_field_op_batch(c, BLSBN254_OP_FP12_MUL, a, b, n, out);
+}
+int blsbn254_gt_pow_batch(blsbn254_ctx* c, const uint8_t* gt, const uint8_t* scalars, size_t n, uint8_t* out) {
+  if (!c || (n && (!gt || !scalars || !out))) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->in_a.reserve(384 * n)); HIPCHK(c, c->in_b.reserve(32 * n)); HIPCHK(c, c->out.reserve(384 * n)); HIPCHK(c, c->status.reserve(n));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, gt, 384 * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->in_b.p, scalars, 32 * n, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "gt_pow", k_gt_pow, n, (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_b.p, n, (uint8_t*)c->out.p, (uint8_t*)c->status.p);
+  int bad; int rc = first_bad(c, (const uint8_t*)c->status.p, n, 1, 1, &bad);
+  if (rc) return rc;
+  if (bad >= 0) return BLSBN254_ERR_GT;
+  HIPCHK(c, hipMemcpyAsync(out, c->out.p, 384 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+
 // ---------------- compressed codecs
 static int codec_common(blsbn254_ctx* c, const uint8_t* in, size_t n, uint8_t* out, int g2, int mode) {
   if (!c || (n && (!in || !out))) return BLSBN254_E_ARG;
@@ -744,6 +807,7 @@ int blsbn254_sign_batch(blsbn254_ctx* c, const uint8_t* sks, const uint8_t* msgs
   if (rc) return rc;
   if (bad >= 0) return BLSBN254_ERR_SCALAR;
   HIPCHK(c, hipMemcpyAsync(sigs_out, c->out.p, 64 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->in_a.p, 0, 32 * n, c->stream));          // the staged secret keys do not outlive the call
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -758,6 +822,7 @@ int blsbn254_sk_to_pk_batch(blsbn254_ctx* c, const uint8_t* sks, size_t n, uint8
   if (rc) return rc;
   if (bad >= 0) return BLSBN254_ERR_SCALAR;
   HIPCHK(c, hipMemcpyAsync(pks_out, c->out.p, 128 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->in_a.p, 0, 32 * n, c->stream));          // the staged secret keys do not outlive the call
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -778,6 +843,8 @@ int blsbn254_keygen_batch(blsbn254_ctx* c, const uint8_t* ikm, size_t ikm_len, s
   if (rc) return rc;
   if (bad >= 0) return BLSBN254_ERR_SCALAR;
   HIPCHK(c, hipMemcpyAsync(sks_out, c->out.p, 32 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->in_a.p, 0, ikm_len * n, c->stream));     // key material and derived keys do not outlive the call
+  HIPCHK(c, hipMemsetAsync(c->out.p, 0, 32 * n, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -814,6 +881,7 @@ int blsbn254_pop_prove_batch(blsbn254_ctx* c, const uint8_t* sks, size_t n, cons
   if (rc) return rc;
   if (bad >= 0) return BLSBN254_ERR_SCALAR;
   HIPCHK(c, hipMemcpyAsync(proofs_out, c->out.p, 64 * n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->in_a.p, 0, 32 * n, c->stream));          // the staged secret keys do not outlive the call
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }

@@ -6,13 +6,6 @@
 #include "kernels.h"
 using namespace bn;
 
-__device__ inline void write_ballot(uint8_t* bitmap, size_t n, size_t i, bool bit) {
-  unsigned long long m = __ballot(bit);
-  unsigned lane = threadIdx.x & 63;
-  size_t base = (i - lane) >> 3;                       // first byte of this wave's 64 tuples
-  size_t nbytes = (n + 7) >> 3;
-  if (lane < 8 && base + lane < nbytes) bitmap[base + lane] = (uint8_t)(m >> (8 * lane));
-}
 
 // mode 0: verify -> bitmap bit = flags ok && subgroup ok && result == 1 ; mode 1/2: Gt bytes ; mode 3: *is_one (n == 1)
 // mode 4: gt_bytes[i] = (result == 1) as one byte per element (RLC group check)

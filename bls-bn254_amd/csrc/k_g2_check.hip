@@ -5,13 +5,6 @@
 #include "kernels.h"
 using namespace bn;
 
-__device__ inline void write_ballot(uint8_t* bitmap, size_t n, size_t i, bool bit) {
-  unsigned long long m = __ballot(bit);
-  unsigned lane = threadIdx.x & 63;
-  size_t base = (i - lane) >> 3;                       // first byte of this wave's 64 tuples
-  size_t nbytes = (n + 7) >> 3;
-  if (lane < 8 && base + lane < nbytes) bitmap[base + lane] = (uint8_t)(m >> (8 * lane));
-}
 BN_KERNEL k_g2_check(const uint8_t* g2, size_t n, uint8_t* ok_bytes, uint8_t* bitmap) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   bool ok = i < n ? lane_g2_check(g2 + 128 * i) : false;

@@ -5,13 +5,6 @@
 #include "kernels.h"
 using namespace bn;
 
-__device__ inline void write_ballot(uint8_t* bitmap, size_t n, size_t i, bool bit) {
-  unsigned long long m = __ballot(bit);
-  unsigned lane = threadIdx.x & 63;
-  size_t base = (i - lane) >> 3;                       // first byte of this wave's 64 tuples
-  size_t nbytes = (n + 7) >> 3;
-  if (lane < 8 && base + lane < nbytes) bitmap[base + lane] = (uint8_t)(m >> (8 * lane));
-}
 
 __device__ inline void store_g1p(int32_t* ws, size_t stride, const G1P& p) {
   store_fp(ws, stride, p.x); store_fp(ws + 9 * stride, stride, p.y); store_fp(ws + 18 * stride, stride, p.z);

@@ -27,7 +27,7 @@ __device__ inline G1P g1_mul_u64(const G1P& p, uint64_t k) {
   }
   return acc;
 }
-// Per tuple: eligibility, r_i = SHA-256(seed || i || pk_i || sig_i)[0..8) (non-zero), A_i = r_i sig_i (projective,
+// Per tuple: eligibility, r_i = SHA-256(seed || i || pk_i || sig_i || H(msg_i))[0..8) (non-zero), A_i = r_i sig_i (projective,
 // a_ws, stride n_pad), B_i = r_i H_i (affine limbs, b_ws, stride n).  Lanes n <= i < n_pad are padding: identity / not eligible.
 BN_KERNEL k_rlc_prep(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, const uint8_t* sub_ok, const uint8_t* seed,
                      size_t n, size_t n_pad, int32_t* a_ws, int32_t* b_ws, uint8_t* elig) {
@@ -45,10 +45,15 @@ BN_KERNEL k_rlc_prep(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_w
     sha256_update(s, seed, 32);
     for (int k = 0; k < 8; ++k) sha256_byte(s, (uint8_t)((uint64_t)i >> (8 * k)));
     sha256_update(s, pks + 128 * i, 128); sha256_update(s, sigs + 64 * i, 64);
+    // bind the message too, through its hash point H(msg_i) (canonical Montgomery limbs as k_hash_to_g1 stored them)
+    for (int k = 0; k < 18; ++k) {
+      uint32_t v = (uint32_t)h_ws[(size_t)k * n + i];
+      sha256_byte(s, (uint8_t)v); sha256_byte(s, (uint8_t)(v >> 8)); sha256_byte(s, (uint8_t)(v >> 16)); sha256_byte(s, (uint8_t)(v >> 24));
+    }
     uint8_t dg[32]; sha256_final(s, dg);
     uint64_t r = 0;
     for (int k = 0; k < 8; ++k) r = (r << 8) | dg[k];
-    r |= 1;                                                                               // never zero
+    r = r ? r : 1;                                                                        // never zero; all 64 bits of the digest are kept
     G1A h; h.x = load_fp(h_ws + i, n); h.y = load_fp(h_ws + 9 * n + i, n); h.inf = false;
     G1A gp = B;
     sig.x = fp_select(ok, sig.x, gp.x); sig.y = fp_select(ok, sig.y, gp.y); sig.inf = false;

@@ -9,6 +9,18 @@
 #endif
 #define BN_KERNEL __global__ void __launch_bounds__(256, BN_WAVES_PER_SIMD)
 
+#if defined(__HIPCC__)
+// One validity bit per tuple, written as the wave's 64-bit ballot: lanes 0..7 store one byte each (LSB-first bitmap).
+// Every lane of the wave must call it (lanes past n pass bit = false).
+__device__ inline void write_ballot(uint8_t* bitmap, size_t n, size_t i, bool bit) {
+  unsigned long long m = __ballot(bit);
+  unsigned lane = threadIdx.x & 63;
+  size_t base = (i - lane) >> 3;                       // first byte of this wave's 64 tuples
+  size_t nbytes = (n + 7) >> 3;
+  if (lane < 8 && base + lane < nbytes) bitmap[base + lane] = (uint8_t)(m >> (8 * lane));
+}
+#endif
+
 BN_KERNEL k_hash_to_g1(const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
                        int32_t* h_ws, uint8_t* out_bytes, int mode);
 BN_KERNEL k_hash_to_g2(const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
@@ -46,6 +58,8 @@ BN_KERNEL k_fp12_mul_elem(int32_t* a, size_t sa, const int32_t* b, size_t sb, si
 BN_KERNEL k_g1p_to_bytes(const int32_t* ws, size_t stride, size_t m, uint8_t* out);
 BN_KERNEL k_rlc_gather(const uint32_t* idx, size_t m, const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n,
                        const uint8_t* sub_ok, uint8_t* c_pks, uint8_t* c_sigs, int32_t* c_h, uint8_t* c_sub);
+BN_KERNEL k_field_op(int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status);
+BN_KERNEL k_gt_pow(const uint8_t* gt, const uint8_t* scalars, size_t n, uint8_t* out, uint8_t* status);
 BN_KERNEL k_lagrange(const uint8_t* ids, size_t t, uint8_t* scalars, uint8_t* status);
 __global__ void __launch_bounds__(256) k_valu_peak(uint32_t* out, uint32_t seed, int iters, int kind, uint64_t* stamps);
 __global__ void k_status_reduce(const uint8_t* status, size_t n, uint8_t want_mask, uint8_t want_val, int* first_bad);

@@ -194,11 +194,15 @@ class Engine:
 
     def verify_batch_rlc(self, pks, msgs, sigs, dst=DEFAULT_DST, seed=None):
         """Same bitmap as verify_batch, via random linear combinations (one final exponentiation per 16 tuples,
-        exact re-verification of failing groups).  seed: 32 random bytes drawn after the batch is fixed."""
+        exact re-verification of failing groups).  seed = None: the library draws it from the OS inside the call
+        (production); a caller seed is for reproducible tests only."""
         n = len(msgs)
-        seed = os.urandom(32) if seed is None else seed
         data, off = pack_messages(msgs)
-        a, pa = _inbuf(pks, 128 * n); m, pm = _inbuf(data); s, ps = _inbuf(sigs, 64 * n); d, pd = _inbuf(dst); sd, psd = _inbuf(seed, 32)
+        a, pa = _inbuf(pks, 128 * n); m, pm = _inbuf(data); s, ps = _inbuf(sigs, 64 * n); d, pd = _inbuf(dst)
+        if seed is None:
+            sd, psd = None, ctypes.cast(None, _u8p)
+        else:
+            sd, psd = _inbuf(seed, 32)
         o, po = _outbuf((n + 7) // 8)
         self._chk(self._lib.blsbn254_verify_batch_rlc(self._ctx, pa, pm, off.ctypes.data_as(_u64p), ps, ctypes.c_size_t(n), pd,
                                                       ctypes.c_size_t(len(dst)), psd, po))
@@ -238,6 +242,33 @@ class Engine:
         a, pa = _inbuf(ids, 32 * t); s, ps = _inbuf(partial_sigs, 64 * t); o, po = _outbuf(64)
         self._chk(self._lib.blsbn254_threshold_combine(self._ctx, pa, ps, ctypes.c_size_t(t), po))
         return o.tobytes()
+
+    # ---- Gt group operations and the field-primitive debug ABI
+    FIELD_OP_WIDTH = {**{k: 32 for k in range(0, 9)}, **{k: 64 for k in range(16, 22)}, **{k: 192 for k in range(32, 36)},
+                      **{k: 384 for k in range(48, 57)}}
+    FIELD_OP_BINARY = (0, 3, 4, 16, 32, 48, 56)
+
+    def field_op_batch(self, op, a, b, n):
+        """One field / tower primitive element-wise (op = BLSBN254_OP_* of the header); n * width bytes back."""
+        w = self.FIELD_OP_WIDTH[op]
+        x, px = _inbuf(a, w * n); o, po = _outbuf(w * n)
+        if op in self.FIELD_OP_BINARY:
+            y, py = _inbuf(b, w * n)
+        else:
+            y, py = None, ctypes.cast(None, _u8p)
+        self._chk(self._lib.blsbn254_field_op_batch(self._ctx, ctypes.c_int(op), px, py, ctypes.c_size_t(n), po))
+        return o[:w * n].tobytes()
+
+    def gt_mul_batch(self, a, b, n):
+        x, px = _inbuf(a, 384 * n); y, py = _inbuf(b, 384 * n); o, po = _outbuf(384 * n)
+        self._chk(self._lib.blsbn254_gt_mul_batch(self._ctx, px, py, ctypes.c_size_t(n), po))
+        return o[:384 * n].tobytes()
+
+    def gt_pow_batch(self, gt, scalars, n):
+        """Gt::mul_by_scalar (pairings.rs:585-600): gt_i ^ k_i, k_i = 32 bytes big-endian."""
+        x, px = _inbuf(gt, 384 * n); k, pk = _inbuf(scalars, 32 * n); o, po = _outbuf(384 * n)
+        self._chk(self._lib.blsbn254_gt_pow_batch(self._ctx, px, pk, ctypes.c_size_t(n), po))
+        return o[:384 * n].tobytes()
 
     # ---- compressed codecs
     def _codec(self, fn, data, n, isz, osz):
@@ -338,3 +369,73 @@ class Engine:
             nm = names.raw[32 * i:32 * i + 32].split(b"\0")[0].decode()
             out[nm] = {"launches": int(launches[i]), "total_ms": float(ms[i])}
         return out
+
+
+class MultiEngine:
+    """blsbn254_multi: one context per listed GPU, one host thread per context per call.
+    An ordinal may be listed twice (two contexts on one GPU)."""
+
+    def __init__(self, devices):
+        self._lib = load_library()
+        self._lib.blsbn254_multi_last_error.restype = ctypes.c_char_p
+        self._lib.blsbn254_multi_ctx.restype = ctypes.c_void_p
+        self._m = ctypes.c_void_p()
+        devs = (ctypes.c_int * len(devices))(*devices)
+        rc = self._lib.blsbn254_multi_create(devs, ctypes.c_int(len(devices)), ctypes.byref(self._m))
+        if rc != 0:
+            self._m = None
+            raise Bn254Error(rc)
+        self.devices = list(devices)
+
+    def close(self):
+        if getattr(self, "_m", None):
+            self._lib.blsbn254_multi_destroy(self._m)
+            self._m = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != 0:
+            detail = self._lib.blsbn254_multi_last_error(self._m).decode() if rc < 0 else ""
+            raise _ERR.get(rc, Bn254Error)(rc, detail)
+
+    def device_count(self):
+        return int(self._lib.blsbn254_multi_device_count(self._m))
+
+    def verify_batch(self, pks, msgs, sigs, dst=DEFAULT_DST):
+        n = len(msgs)
+        data, off = pack_messages(msgs)
+        a, pa = _inbuf(pks, 128 * n); m, pm = _inbuf(data); s, ps = _inbuf(sigs, 64 * n); d, pd = _inbuf(dst)
+        o, po = _outbuf((n + 7) // 8)
+        self._chk(self._lib.blsbn254_verify_batch_multi(self._m, pa, pm, off.ctypes.data_as(_u64p), ps, ctypes.c_size_t(n), pd,
+                                                        ctypes.c_size_t(len(dst)), po))
+        return o[:(n + 7) // 8].tobytes()
+
+    def aggregate_verify(self, pks, msgs, agg_sig, dst=DEFAULT_DST):
+        n = len(msgs)
+        data, off = pack_messages(msgs)
+        a, pa = _inbuf(pks, 128 * n); m, pm = _inbuf(data); s, ps = _inbuf(agg_sig, 64); d, pd = _inbuf(dst)
+        valid = ctypes.c_int(0)
+        self._chk(self._lib.blsbn254_aggregate_verify_multi(self._m, pa, pm, off.ctypes.data_as(_u64p), ctypes.c_size_t(n), ps, pd,
+                                                            ctypes.c_size_t(len(dst)), ctypes.byref(valid)))
+        return bool(valid.value)
+
+    def verify_batch_dev(self, d_pks, d_msgs, d_off, d_sigs, counts, d_full_bitmaps, dst=DEFAULT_DST):
+        """Device-resident shards (lists of raw device pointers, one per device) -> the full bitmap on every device
+        (RCCL all-reduce of the disjoint word arrays)."""
+        g = len(self.devices)
+        vp = lambda xs: (ctypes.c_void_p * g)(*xs)
+        cnt = (ctypes.c_size_t * g)(*counts)
+        d, pd = _inbuf(dst)
+        self._chk(self._lib.blsbn254_verify_batch_multi_dev(self._m, vp(d_pks), vp(d_msgs), vp(d_off), vp(d_sigs), cnt, pd,
+                                                            ctypes.c_size_t(len(dst)), vp(d_full_bitmaps)))

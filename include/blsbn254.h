@@ -49,9 +49,11 @@ typedef struct blsbn254_ctx blsbn254_ctx;
 #define BLSBN254_E_HIP (-2)
 #define BLSBN254_E_NOMEM (-3)
 #define BLSBN254_E_NO_DEVICE (-4)
+#define BLSBN254_E_RCCL (-5)
 
 /* One context per GPU (device = HIP ordinal).  Replaces nothing in the reference (it has no
- * state); owns the stream, the workspace and the resident -G2gen line table. */
+ * state); owns the stream, the workspace and the resident -G2gen line table.  The N-GPU form of SURVEY.md 8b
+ * (a ctx over a device list) is blsbn254_multi below, built from these. */
 int blsbn254_ctx_create(int device, blsbn254_ctx** out);
 void blsbn254_ctx_destroy(blsbn254_ctx* ctx);
 const char* blsbn254_strerror(int code);
@@ -92,7 +94,11 @@ int blsbn254_g2_check_batch(blsbn254_ctx* ctx, const uint8_t* g2, size_t n, uint
  *           e(sig_i, -G2gen) * e(H(msg_i), pk_i) == 1 */
 int blsbn254_verify_batch(blsbn254_ctx* ctx, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off,
                           const uint8_t* sigs, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* valid_bitmap);
-/* valid = prod_i e(H(msg_i), pk_i) * e(agg_sig, -G2gen) == 1, every pk_i valid, n >= 1 */
+/* valid = prod_i e(H(msg_i), pk_i) * e(agg_sig, -G2gen) == 1, every pk_i valid, n >= 1.
+ * PRECONDITION (rogue-key protection, IETF BLS section 3): this is CoreAggregateVerify -- the algebraic check only.  With a
+ * basic-scheme tag (the suggested default DST ends in _NUL_) the CALLER must reject batches with repeated messages;
+ * alternatively use a proof-of-possession tag (_POP_) and only keys whose proof passed blsbn254_pop_verify_batch.
+ * The library does not detect duplicate messages (the reference has no BLS layer to pin either behaviour). */
 int blsbn254_aggregate_verify(blsbn254_ctx* ctx, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
                               const uint8_t agg_sig[64], const uint8_t* dst, size_t dst_len, int* valid);
 /* The same check split for sharding over GPUs: every rank reduces ITS (pk_i, msg_i) to one
@@ -105,9 +111,12 @@ int blsbn254_aggregate_finish(blsbn254_ctx* ctx, const uint8_t* partials /* k*38
 /* Same result as blsbn254_verify_batch (same bitmap), computed with random linear combinations (SURVEY.md 8f
  * rank 4): groups of 16 tuples share ONE final exponentiation,
  *   prod_i [e(sig_i,-G2gen) e(H_i,pk_i)]^(r_i) = e(sum r_i sig_i, -G2gen) * prod_i e(r_i H_i, pk_i),
- * with 64-bit r_i = SHA-256(seed || i || pk_i || sig_i); a group whose product is not 1 is re-verified tuple by
- * tuple with the exact path, so a bit can only differ from verify_batch's with probability 2^-64 per group
- * (an invalid group passing).  seed: 32 bytes the caller draws at random AFTER the batch is fixed. */
+ * with 64-bit r_i = SHA-256(seed || i || pk_i || sig_i || H(msg_i)) (non-zero); a group whose product is not 1 is
+ * re-verified tuple by tuple with the exact path, so a bit can only differ from verify_batch's when an invalid group
+ * passes: probability about 2^-64 per group for a seed the adversary cannot predict.
+ * seed = NULL (the production setting): the library draws 32 bytes from the OS (getrandom) inside the call, i.e. after
+ * the batch is fixed.  A caller-supplied seed exists for reproducible tests; soundness then rests on that seed being
+ * fresh and secret -- never reuse one, never derive it from public data. */
 int blsbn254_verify_batch_rlc(blsbn254_ctx* ctx, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off,
                               const uint8_t* sigs, size_t n, const uint8_t* dst, size_t dst_len,
                               const uint8_t seed[32], uint8_t* valid_bitmap);
@@ -120,7 +129,8 @@ int blsbn254_threshold_combine(blsbn254_ctx* ctx, const uint8_t* ids, const uint
 /* ---- signing side (also used to generate large synthetic batches) ----------- */
 /* sig_i = [sk_i] H(msg_i): G1Projective::hash (g1.rs:910-919) + Mul<Scalar> (g1.rs:518-534, :821-841).
  * sks = n x 32 B big-endian, each < r (else BLSBN254_ERR_SCALAR).  Not constant time (the reference's
- * ladder is; a verification engine handles public data -- do not use with production secrets). */
+ * ladder is; a verification engine handles public data -- do not use with production secrets).  The staged
+ * secret keys are zeroed in device memory before the signing-side entry points return. */
 int blsbn254_sign_batch(blsbn254_ctx* ctx, const uint8_t* sks, const uint8_t* msgs, const uint64_t* off, size_t n,
                         const uint8_t* dst, size_t dst_len, uint8_t* sigs_out);
 /* pk_i = [sk_i] G2gen: Mul<Scalar> for G2Projective (g2.rs:866-886) */
@@ -165,6 +175,78 @@ int blsbn254_pairing_batch_dev(blsbn254_ctx* ctx, const uint8_t* d_g1, const uin
                                uint8_t* d_status /* n bytes or NULL */);
 int blsbn254_ctx_synchronize(blsbn254_ctx* ctx);
 void* blsbn254_ctx_stream(blsbn254_ctx* ctx); /* the hipStream_t */
+
+/* ---- Gt group operations and the field-primitive debug ABI ------------------------------------------------ */
+/* Gt is written multiplicatively: the reference's `Gt + Gt` is the Fp12 product (pairings.rs:245-381 trait glue over
+ * fp12.rs:203-210) and Gt::mul_by_scalar (pairings.rs:585-600) is gt^k, k = 32 bytes big-endian (any 256-bit value).
+ * Operands that do not decode (a coefficient >= p) return BLSBN254_ERR_GT. */
+int blsbn254_gt_mul_batch(blsbn254_ctx* ctx, const uint8_t* a /* n*384 */, const uint8_t* b /* n*384 */, size_t n, uint8_t* out);
+int blsbn254_gt_pow_batch(blsbn254_ctx* ctx, const uint8_t* gt /* n*384 */, const uint8_t* scalars /* n*32 */, size_t n, uint8_t* out);
+/* One field / tower primitive applied element-wise to n operands: the isolated parity pin of the device arithmetic
+ * (the reference's fp6.rs / fp12.rs have no test vectors; tests fuzz this against the CPU oracle).
+ * Element bytes are canonical big-endian coefficients: Fp 32 B; Fp2 64 B = c0 || c1 (NOT the c1 || c0 wire order of G2);
+ * Fp6 192 B = c0.c0 c0.c1 c1.c0 c1.c1 c2.c0 c2.c1; Fp12 384 B in Gt::to_repr order.  b is read by the binary ops only
+ * (pass NULL otherwise); a coefficient >= p returns BLSBN254_ERR_GT. */
+#define BLSBN254_OP_FP_MUL 0          /* Fp::multiply        fp.rs:404-407 */
+#define BLSBN254_OP_FP_SQR 1          /* Fp::square          fp.rs:409-412 */
+#define BLSBN254_OP_FP_INV 2          /* Fp::invert          fp.rs:207-210 (0 -> 0) */
+#define BLSBN254_OP_FP_ADD 3          /* fp.rs:388 */
+#define BLSBN254_OP_FP_SUB 4          /* fp.rs:396 */
+#define BLSBN254_OP_FP_NEG 5          /* fp.rs:400 */
+#define BLSBN254_OP_FP_SQRT 6         /* a root of a (sqrt_ratio, fp.rs:212-243: a^((p+1)/4)), or 0 when a is not a square */
+#define BLSBN254_OP_FP_IS_SQUARE 7    /* is_square fp.rs:428-431 as the field element 1 / 0 */
+#define BLSBN254_OP_FP_MUL_3B 8       /* mul_by_3b = 9 a      fp.rs:414 */
+#define BLSBN254_OP_FP2_MUL 16        /* fp2.rs:377-390 */
+#define BLSBN254_OP_FP2_SQR 17        /* fp2.rs:392-402 */
+#define BLSBN254_OP_FP2_INV 18        /* fp2.rs:161-166 */
+#define BLSBN254_OP_FP2_MUL_XI 19     /* times the Fp6 non-residue 9 + u (E1: not fp2.rs:415-420's 1 + u) */
+#define BLSBN254_OP_FP2_CONJ 20       /* fp2.rs:428-437 */
+#define BLSBN254_OP_FP2_SQRT 21       /* fp2.rs:172-218, a root or 0 */
+#define BLSBN254_OP_FP6_MUL 32        /* fp6.rs:225-242 */
+#define BLSBN254_OP_FP6_SQR 33        /* a * a (fp6.rs:244-259 is defective, E2) */
+#define BLSBN254_OP_FP6_INV 34        /* fp6.rs:261-287, denominator corrected */
+#define BLSBN254_OP_FP6_MUL_V 35      /* mul_by_non_residue fp6.rs:146-152 */
+#define BLSBN254_OP_FP12_MUL 48       /* fp12.rs:203-210 */
+#define BLSBN254_OP_FP12_SQR 49       /* fp12.rs:170-180 */
+#define BLSBN254_OP_FP12_INV 50       /* fp12.rs:212-219 */
+#define BLSBN254_OP_FP12_CONJ 51      /* fp12.rs:131-137 */
+#define BLSBN254_OP_FP12_FROB1 52     /* frobenius_map^1..3 with the xi^((p^k-1)/6) constants (E3) */
+#define BLSBN254_OP_FP12_FROB2 53
+#define BLSBN254_OP_FP12_FROB3 54
+#define BLSBN254_OP_FP12_CYC_SQR 55   /* cyclotomic_square pairings.rs:68-115 (the Granger-Scott formula on any input) */
+#define BLSBN254_OP_FP12_MUL_034 56   /* sparse line product, a * (b.c0.c0 + b.c1.c0 w + b.c1.c1 v w)  (E7) */
+int blsbn254_field_op_batch(blsbn254_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out);
+
+/* ---- multi-device (SURVEY.md 8b "ctx over a device list", 8e) -------------------------------------------- */
+/* A blsbn254_multi owns one ctx (stream + workspace) per entry of `devices` (HIP ordinals; an ordinal may be listed more
+ * than once -- two contexts on one GPU -- which is how a single-GPU box exercises this path).  A call runs one host
+ * thread per entry.  Verify tuples are independent (the per-term independence of multi_miller_loop,
+ * pairings.rs:819-824): device g takes a contiguous range of the batch (boundaries at multiples of 8 tuples) and
+ * there is no data-path collective.  Calls on one blsbn254_multi must be externally serialized. */
+typedef struct blsbn254_multi blsbn254_multi;
+int blsbn254_multi_create(const int* devices, int ndev, blsbn254_multi** out);
+void blsbn254_multi_destroy(blsbn254_multi* m);
+int blsbn254_multi_device_count(blsbn254_multi* m);
+blsbn254_ctx* blsbn254_multi_ctx(blsbn254_multi* m, int i); /* the i-th per-device ctx (owned by m) */
+const char* blsbn254_multi_last_error(blsbn254_multi* m);
+/* blsbn254_verify_batch over all devices of m: same arguments, same bitmap.  Host pointers in and out; every device
+ * copies its slice of the bitmap into valid_bitmap (a host gather of disjoint slices). */
+int blsbn254_verify_batch_multi(blsbn254_multi* m, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off,
+                                const uint8_t* sigs, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* valid_bitmap);
+/* blsbn254_aggregate_verify over all devices of m: per-device blsbn254_aggregate_partial, the 384-byte partials are
+ * gathered on the host, one blsbn254_aggregate_finish on the first device. */
+int blsbn254_aggregate_verify_multi(blsbn254_multi* m, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
+                                    const uint8_t agg_sig[64], const uint8_t* dst, size_t dst_len, int* valid);
+/* Device-resident N-GPU verify with the bitmap exchange of SURVEY.md 8e.  Device g already holds ITS shard in HBM:
+ * d_pks[g] (counts[g] x 128), d_msgs[g] with d_off[g] (counts[g] + 1 offsets relative to d_msgs[g]), d_sigs[g]
+ * (counts[g] x 64); counts[g] is a multiple of 32 for every g but the last.  Every device writes its bits into a
+ * zeroed full-length word array and the arrays are summed by ONE ncclAllReduce(ncclSum, ncclUint32) over xGMI
+ * (disjoint bit sets: SUM == OR; RCCL has no bitwise op), so that on return d_full_bitmap[g] (4 * ceil(N / 32) bytes
+ * on device g, N = sum of counts) holds the bitmap of the whole batch in global order on EVERY device.  librccl is
+ * loaded with dlopen at first use (BLSBN254_E_RCCL if absent or on an RCCL error, e.g. one ordinal listed twice). */
+int blsbn254_verify_batch_multi_dev(blsbn254_multi* m, const uint8_t* const* d_pks, const uint8_t* const* d_msgs,
+                                    const uint64_t* const* d_off, const uint8_t* const* d_sigs, const size_t* counts,
+                                    const uint8_t* dst, size_t dst_len, uint8_t* const* d_full_bitmap);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------------ */
 /* When enabled, every kernel launch on the ctx is bracketed by HIP events on the ctx stream;

@@ -208,6 +208,55 @@ pub fn threshold_combine(ids: &[[u8; 32]], partials: &[[u8; 64]]) -> Result<[u8;
     Ok(out)
 }
 
+// ---------------------------------------------------------------- N GPUs of one node
+
+/// All GPUs named in `BLSBN254_DEVICES` (comma-separated HIP ordinals, default "0"): one context and one host thread per
+/// GPU inside the library, contiguous shards, no data-path collective (`blsbn254_multi`).
+struct MultiEngine(*mut ffi::Multi);
+unsafe impl Send for MultiEngine {}
+
+fn multi_engine() -> &'static Mutex<MultiEngine> {
+    static ENGINE: OnceLock<Mutex<MultiEngine>> = OnceLock::new();
+    ENGINE.get_or_init(|| {
+        let devs: Vec<c_int> = std::env::var("BLSBN254_DEVICES").unwrap_or_else(|_| "0".into())
+            .split(',').filter_map(|s| s.trim().parse::<c_int>().ok()).collect();
+        let mut m: *mut ffi::Multi = core::ptr::null_mut();
+        let rc = unsafe { ffi::blsbn254_multi_create(devs.as_ptr(), devs.len() as c_int, &mut m) };
+        assert!(rc == 0 && !m.is_null(), "blsbn254_multi_create failed with code {rc}");
+        Mutex::new(MultiEngine(m))
+    })
+}
+
+/// `verify_batch` sharded over every configured GPU; same result as the single-GPU call.
+pub fn verify_batch_multi(pks: &[[u8; 128]], msgs: &[&[u8]], sigs: &[[u8; 64]], dst: &[u8]) -> Vec<bool> {
+    assert!(pks.len() == msgs.len() && msgs.len() == sigs.len());
+    let n = pks.len();
+    let (data, off) = pack(msgs);
+    let pk: Vec<u8> = pks.iter().flatten().copied().collect();
+    let sg: Vec<u8> = sigs.iter().flatten().copied().collect();
+    let mut bm = vec![0u8; (n + 7) / 8];
+    let guard = multi_engine().lock().expect("engine mutex poisoned");
+    check(unsafe {
+        ffi::blsbn254_verify_batch_multi(guard.0, pk.as_ptr(), data.as_ptr(), off.as_ptr(), sg.as_ptr(), n, dst.as_ptr(), dst.len(), bm.as_mut_ptr())
+    })
+    .expect("per-tuple failures are reported in the bitmap");
+    bits(&bm, n)
+}
+
+/// `aggregate_verify` sharded over every configured GPU (per-GPU Fp12 partial products, one final exponentiation).
+pub fn aggregate_verify_multi(pks: &[[u8; 128]], msgs: &[&[u8]], agg_sig: &[u8; 64], dst: &[u8]) -> bool {
+    assert_eq!(pks.len(), msgs.len());
+    let (data, off) = pack(msgs);
+    let pk: Vec<u8> = pks.iter().flatten().copied().collect();
+    let mut valid: c_int = 0;
+    let guard = multi_engine().lock().expect("engine mutex poisoned");
+    check(unsafe {
+        ffi::blsbn254_aggregate_verify_multi(guard.0, pk.as_ptr(), data.as_ptr(), off.as_ptr(), pks.len(), agg_sig.as_ptr(), dst.as_ptr(), dst.len(), &mut valid)
+    })
+    .expect("invalid inputs yield valid = 0");
+    valid == 1
+}
+
 #[cfg(test)]
 mod tests {
     use super::*;

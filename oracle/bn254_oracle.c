@@ -1241,6 +1241,71 @@ int oracle_gt_mul(const uint8_t a[384], const uint8_t b[384], uint8_t out[384]) 
   f12_to_bytes(out, f12_mul(x, y));
   return 0;
 }
+/* One field / tower primitive element-wise over n operands: the CPU side of the device's debug ABI
+ * (blsbn254_field_op_batch, same op codes and byte layouts; include/blsbn254.h BLSBN254_OP_*). */
+static int f2_from_c0c1(fp2* a, const uint8_t* in) { return fp_from_be(&a->c0, in) & fp_from_be(&a->c1, in + 32); }
+static void f2_to_c0c1(uint8_t* out, fp2 a) { fp_to_be(out, a.c0); fp_to_be(out + 32, a.c1); }
+static int f6_from_b(fp6* a, const uint8_t* in) { return f2_from_c0c1(&a->c0, in) & f2_from_c0c1(&a->c1, in + 64) & f2_from_c0c1(&a->c2, in + 128); }
+static void f6_to_b(uint8_t* out, fp6 a) { f2_to_c0c1(out, a.c0); f2_to_c0c1(out + 64, a.c1); f2_to_c0c1(out + 128, a.c2); }
+int oracle_field_op_batch(int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
+  init();
+  for (size_t i = 0; i < n; ++i) {
+    if (op >= 0 && op <= 8) {
+      fp x, y = FP_ONE, r;
+      if (!fp_from_be(&x, a + 32 * i) || (b && !fp_from_be(&y, b + 32 * i))) return 4;
+      switch (op) {
+        case 0: r = fp_mul(x, y); break;
+        case 1: r = fp_sqr(x); break;
+        case 2: r = fp_inv(x); break;
+        case 3: r = fp_add(x, y); break;
+        case 4: r = fp_sub(x, y); break;
+        case 5: r = fp_neg(x); break;
+        case 6: if (!fp_sqrt(&r, x)) r = FP_ZERO; break;
+        case 7: r = fp_is_square(x) ? FP_ONE : FP_ZERO; break;
+        default: r = fp_mul_b3(x); break;
+      }
+      fp_to_be(out + 32 * i, r);
+    } else if (op >= 16 && op <= 21) {
+      fp2 x, y = F2_ONE, r;
+      if (!f2_from_c0c1(&x, a + 64 * i) || (b && !f2_from_c0c1(&y, b + 64 * i))) return 4;
+      switch (op) {
+        case 16: r = f2_mul(x, y); break;
+        case 17: r = f2_sqr(x); break;
+        case 18: r = f2_inv(x); break;
+        case 19: r = f2_mul_xi(x); break;
+        case 20: r = f2_conj(x); break;
+        default: if (!f2_sqrt(&r, x)) r = F2_ZERO; break;
+      }
+      f2_to_c0c1(out + 64 * i, r);
+    } else if (op >= 32 && op <= 35) {
+      fp6 x, y = F6_ONE, r;
+      if (!f6_from_b(&x, a + 192 * i) || (b && !f6_from_b(&y, b + 192 * i))) return 4;
+      switch (op) {
+        case 32: r = f6_mul(x, y); break;
+        case 33: r = f6_sqr(x); break;
+        case 34: r = f6_inv(x); break;
+        default: r = f6_mul_v(x); break;
+      }
+      f6_to_b(out + 192 * i, r);
+    } else if (op >= 48 && op <= 56) {
+      fp12 x, y = F12_ONE, r;
+      if (!f12_from_bytes(&x, a + 384 * i) || (b && !f12_from_bytes(&y, b + 384 * i))) return 4;
+      switch (op) {
+        case 48: r = f12_mul(x, y); break;
+        case 49: r = f12_sqr(x); break;
+        case 50: r = f12_inv(x); break;
+        case 51: r = f12_conj(x); break;
+        case 52: r = f12_frob(x, 1); break;
+        case 53: r = f12_frob(x, 2); break;
+        case 54: r = f12_frob(x, 3); break;
+        case 55: r = f12_cyclotomic_sqr(x); break;
+        default: r = f12_mul_by_034(x, y.c0.c0, y.c1.c0, y.c1.c1); break;
+      }
+      f12_to_bytes(out + 384 * i, r);
+    } else return -1;
+  }
+  return 0;
+}
 int oracle_gt_pow(const uint8_t gt[384], const uint8_t k_be[32], uint8_t out[384]) {   /* Gt::mul_by_scalar, pairings.rs:585-600 */
   init();
   fp12 x, acc = F12_ONE; u64 k[4];

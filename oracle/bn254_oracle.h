@@ -65,6 +65,8 @@ void oracle_g2_generator(uint8_t out[128]);
 int oracle_sk_to_pk(const uint8_t sk_be[32], uint8_t pk[128]);
 int oracle_sign(const uint8_t sk_be[32], const uint8_t* msg, size_t msg_len,
                 const uint8_t* dst, size_t dst_len, uint8_t sig[64]);
+/* field / tower primitives, element-wise; op codes and byte layouts of include/blsbn254.h (BLSBN254_OP_*); b may be NULL for unary ops */
+int oracle_field_op_batch(int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out);
 int oracle_gt_pow(const uint8_t gt[384], const uint8_t scalar_be[32], uint8_t out[384]);
 int oracle_gt_mul(const uint8_t a[384], const uint8_t b[384], uint8_t out[384]);
 int oracle_fr_lagrange_at_zero(const uint8_t* ids, size_t t, uint8_t* out /* t*32 BE */);

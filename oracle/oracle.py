@@ -240,6 +240,23 @@ def verify_batch_refstyle(pks, msgs, sigs, dst, nthreads=1):
     return o[:(n + 7) // 8].tobytes()
 
 
+FIELD_OP_WIDTH = {**{k: 32 for k in range(0, 9)}, **{k: 64 for k in range(16, 22)}, **{k: 192 for k in range(32, 36)},
+                  **{k: 384 for k in range(48, 57)}}
+FIELD_OP_BINARY = (0, 3, 4, 16, 32, 48, 56)
+
+
+def field_op_batch(op, a, b, n):
+    """Element-wise field / tower primitive (op codes of include/blsbn254.h); returns n * width bytes."""
+    w = FIELD_OP_WIDTH[op]
+    x, px = _buf(a); o, po = _out(w * n)
+    if op in FIELD_OP_BINARY:
+        y, py = _buf(b)
+    else:
+        y, py = None, ctypes.cast(None, u8p)
+    _chk(lib().oracle_field_op_batch(ctypes.c_int(op), px, py, ctypes.c_size_t(n), po))
+    return o[:w * n].tobytes()
+
+
 def verify_core_counts():
     """Exact Fp mul+sqr counts of the algorithmic unit: (variable-Q Miller pair, fixed-Q pair from table, final exp, table entries)."""
     a = (ctypes.c_uint64 * 4)()

@@ -473,3 +473,67 @@ def test_chunked_entry_points(oracle, pyref, M, monkeypatch):
             e.pairing_batch(bad, g2, m)
     finally:
         e.close()
+
+
+def _rand_coeffs(seed, n, per):
+    """n elements of `per` canonical 32-byte big-endian coefficients (top byte < 0x30 keeps every value below p); the first
+    elements carry the edge values 0, 1, p - 1."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, size=(n * per, 32), dtype=np.uint8)
+    a[:, 0] %= 0x30
+    edge = [0, 1, synth.P - 1, 2, synth.P - 2]
+    for k, v in enumerate(edge[:min(len(edge), n * per)]):
+        a[k] = np.frombuffer(v.to_bytes(32, "big"), dtype=np.uint8)
+    return a.tobytes()
+
+
+@pytest.mark.parametrize("op,per,n", [
+    (0, 1, 1 << 20), (1, 1, 1 << 20), (3, 1, 1 << 20), (4, 1, 1 << 20), (5, 1, 1 << 20), (8, 1, 1 << 20),       # Fp mul sqr add sub neg x9
+    (2, 1, 20000), (6, 1, 20000), (7, 1, 20000),                                                                   # Fp inv sqrt is_square
+    (16, 2, 1 << 18), (17, 2, 1 << 18), (19, 2, 1 << 18), (20, 2, 1 << 18), (18, 2, 20000), (21, 2, 2000),         # Fp2
+    (32, 6, 1 << 17), (33, 6, 1 << 17), (35, 6, 1 << 17), (34, 6, 10000),                                          # Fp6
+    (48, 12, 1 << 16), (49, 12, 1 << 16), (51, 12, 1 << 16), (52, 12, 1 << 16), (53, 12, 1 << 16), (54, 12, 1 << 16),
+    (55, 12, 1 << 16), (56, 12, 1 << 16), (50, 12, 10000)])                                                        # Fp12
+def test_field_primitives_fuzz_vs_oracle(eng, oracle, op, per, n):
+    """Primitive-level parity: every Fp / Fp2 / Fp6 / Fp12 operation of the device arithmetic,
+    element-wise on random operands (up to 2^20 wide), bit-exact against the CPU oracle.  fp6.rs / fp12.rs hold no reference
+    vectors, so this -- with the oracle itself checked against the independent Python model on CPU -- is their isolated pin."""
+    a = _rand_coeffs(1000 + op, n, per)
+    b = _rand_coeffs(2000 + op, n, per) if op in eng.FIELD_OP_BINARY else None
+    got = eng.field_op_batch(op, a, b, n)
+    want = oracle.field_op_batch(op, a, b, n)
+    if got != want:
+        w = 32 * per
+        bad = [i for i in range(n) if got[w * i:w * i + w] != want[w * i:w * i + w]]
+        raise AssertionError("op %d: %d of %d elements differ, first at %d" % (op, len(bad), n, bad[0]))
+
+
+def test_field_op_abi_errors(eng, M):
+    a = (synth.P).to_bytes(32, "big")                       # not canonical
+    with pytest.raises(M.InvalidGtBytes):
+        eng.field_op_batch(1, a, None, 1)
+    with pytest.raises(M.Bn254Error) as e:
+        eng._chk(eng._lib.blsbn254_field_op_batch(eng._ctx, 99, None, None, 1, None))
+    assert e.value.code == -1
+    assert eng.field_op_batch(0, b"", b"", 0) == b""
+
+
+def test_gt_group_ops(eng, oracle, pyref):
+    """Gt multiply and Gt::mul_by_scalar (pairings.rs:585-600) against the oracle; gt^r == 1 (pairings.rs:977-979)."""
+    rnd = random.Random(5)
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    n = 24
+    g1 = b"".join(oracle.g1_mul(G1, rnd.randrange(1, pyref.R)) for _ in range(n))
+    g2 = b"".join(oracle.g2_mul(G2, rnd.randrange(1, pyref.R)) for _ in range(n))
+    gts = eng.pairing_batch(g1, g2, n)
+    ks = [0, 1, 2, pyref.R, pyref.R - 1, (1 << 256) - 1] + [rnd.randrange(1 << 256) for _ in range(n - 6)]
+    kb = b"".join(k.to_bytes(32, "big") for k in ks)
+    got = eng.gt_pow_batch(gts, kb, n)
+    want = b"".join(oracle.gt_pow(gts[384 * i:384 * i + 384], ks[i]) for i in range(n))
+    assert got == want
+    assert got[:384] == ONE_GT and got[384:768] == gts[384:768] and got[384 * 3:384 * 4] == ONE_GT      # k = 0, 1, r
+    rot = gts[384:] + gts[:384]
+    assert eng.gt_mul_batch(gts, rot, n) == b"".join(oracle.gt_mul(gts[384 * i:384 * i + 384], rot[384 * i:384 * i + 384]) for i in range(n))
+    # bilinearity through the new entry points: e(aP, Q) = e(P, Q)^a
+    a = rnd.randrange(1, pyref.R)
+    assert eng.pairing_batch(oracle.g1_mul(G1, a), G2, 1) == eng.gt_pow_batch(eng.pairing_batch(G1, G2, 1), a.to_bytes(32, "big"), 1)

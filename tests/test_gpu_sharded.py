@@ -105,6 +105,74 @@ def test_world2_aggregate_verify_sharded_with_engine(tmp_path, oracle):
         assert np.load(tmp_path / ("a%d.npy" % r)).tolist() == [1, 0]
 
 
+def test_c_abi_multi_device_equals_single(oracle):
+    """blsbn254_multi over [0, 0] (two contexts, two host threads on the one GPU of the box) == blsbn254_verify_batch and
+    == the oracle; aggregate verify likewise (SURVEY.md 8b signature block, 8e)."""
+    import blsbn254_loader
+    M = blsbn254_loader.load()
+    dst = b"TEST_DST"
+    with M.Engine(0) as eng, M.MultiEngine([0, 0]) as me, M.MultiEngine([0, 0, 0]) as me3:
+        assert me.device_count() == 2
+        for n in (1, 7, 8, 9, 37, 600):
+            pks, msgs, sigs, exp = synth.make_batch(oracle, n, dst, invalid_every=3, uniq=12)
+            want = eng.verify_batch(pks, msgs, sigs, dst)
+            assert want == synth.bitmap_of(exp)
+            assert me.verify_batch(pks, msgs, sigs, dst) == want
+            assert me3.verify_batch(pks, msgs, sigs, dst) == want
+        assert me.verify_batch(b"", [], b"", dst) == b""
+        n = 11
+        sks = [synth.sk_of(k) for k in range(n)]
+        pks = b"".join(oracle.sk_to_pk(s) for s in sks)
+        msgs = [synth.msg_of(i) + bytes(i) for i in range(n)]           # ragged lengths: shard offsets are relative
+        agg = oracle.aggregate_sigs(b"".join(oracle.sign(s, m, dst) for s, m in zip(sks, msgs)), n)
+        assert eng.aggregate_verify(pks, msgs, agg, dst) is True
+        assert me.aggregate_verify(pks, msgs, agg, dst) is True and me3.aggregate_verify(pks, msgs, agg, dst) is True
+        bad = list(msgs); bad[n - 1] = b"tampered"
+        assert me.aggregate_verify(pks, bad, agg, dst) is False
+        # a public key outside the subgroup in the second shard
+        pk_bad = pks[:128 * (n - 1)] + synth.NON_SUBGROUP_PK
+        assert me.aggregate_verify(pk_bad, msgs, agg, dst) is False
+        # an undecodable tuple is not an error in verify_batch (bit cleared) on either path
+        pks2, msgs2, sigs2, _ = synth.make_batch(oracle, 16, dst, uniq=4)
+        sigs2 = sigs2[:64 * 9] + b"\xff" * 64 + sigs2[64 * 10:]
+        assert me.verify_batch(pks2, msgs2, sigs2, dst) == eng.verify_batch(pks2, msgs2, sigs2, dst)
+
+
+def test_c_abi_multi_device_resident_rccl(oracle):
+    """Device-resident entry point with the RCCL all-reduce of the bitmap words, on the one device of the box (a
+    one-rank communicator; the N-rank form is the same code path with ncclCommInitAll over N ordinals).  Listing an
+    ordinal twice is an RCCL error, reported as BLSBN254_E_RCCL -- never a silent fallback."""
+    import torch
+    import blsbn254_loader
+    M = blsbn254_loader.load()
+    dst = b"TEST_DST"
+    dev = torch.device("cuda", 0)
+    n = 200
+    pks, msgs, sigs, exp = synth.make_batch(oracle, n, dst, invalid_every=3, uniq=12)
+    data, off = M.engine.pack_messages(msgs)
+    t_pk = torch.frombuffer(bytearray(pks), dtype=torch.uint8).to(dev)
+    t_sg = torch.frombuffer(bytearray(sigs), dtype=torch.uint8).to(dev)
+    t_ms = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+    t_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    nwords = (n + 31) // 32
+    t_full = torch.full((4 * nwords,), 0xAA, dtype=torch.uint8, device=dev)      # must be overwritten, not accumulated into
+    torch.cuda.synchronize()
+    with M.MultiEngine([0]) as me:
+        me.verify_batch_dev([t_pk.data_ptr()], [t_ms.data_ptr()], [t_off.data_ptr()], [t_sg.data_ptr()], [n], [t_full.data_ptr()], dst)
+        got = bytes(t_full.cpu().numpy())
+        assert got[:(n + 7) // 8] == synth.bitmap_of(exp) and not any(got[(n + 7) // 8:])
+    with M.MultiEngine([0, 0]) as me2:
+        t_full2 = torch.zeros(4 * nwords, dtype=torch.uint8, device=dev)
+        half = 96
+        o2 = (off[half:] - off[half]).astype(np.int64)
+        t_off2 = torch.from_numpy(o2).to(dev)
+        with pytest.raises(M.Bn254Error) as e:
+            me2.verify_batch_dev([t_pk.data_ptr(), t_pk.data_ptr() + 128 * half], [t_ms.data_ptr(), t_ms.data_ptr() + int(off[half])],
+                                 [t_off.data_ptr(), t_off2.data_ptr()], [t_sg.data_ptr(), t_sg.data_ptr() + 64 * half], [half, n - half],
+                                 [t_full.data_ptr(), t_full2.data_ptr()], dst)
+        assert e.value.code == -5
+
+
 def test_bench_spawns_its_own_ranks():
     """plain `python bench.py --gpus 2` (WORLD_SIZE unset): the parent starts two ranks before touching the GPU and relays
     rank 0's line; both ranks rehearse on device 0 over gloo (the real run is one rank per GPU over RCCL)."""

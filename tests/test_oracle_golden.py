@@ -271,3 +271,95 @@ def test_reference_style_multiply(oracle, pyref):
     for a, b in [(0, 0), (1, P - 1), (P - 1, P - 1), (2**253, 2**253)] + [(rnd.randrange(P), rnd.randrange(P)) for _ in range(100)]:
         assert oracle.fp_mul_refstyle(a, b) == a * b % P
     assert oracle.bench_fp_mul(True, 1000) > 0 and oracle.bench_fp_mul(False, 1000) > 0
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """The C oracle driven by oracle/asan_check.c, built with -fsanitize=address,undefined (CPU build only: GPU ASan is
+    not available on the pool).  Every entry-point family on small, ragged and malformed inputs."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle"), "-s", "asan_check"], stderr=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(root, "oracle", "_build", "asan_check")], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0"))
+    assert out.returncode == 0 and "asan_check ok" in out.stdout, out.stderr[-3000:]
+
+
+def _rand_fp_bytes(rnd, n, P):
+    vals = [rnd.randrange(P) for _ in range(n)]
+    for k, v in enumerate((0, 1, P - 1, 2, P - 2)):
+        if k < n:
+            vals[k] = v
+    return b"".join(v.to_bytes(32, "big") for v in vals), vals
+
+
+def test_oracle_field_ops_vs_independent_model(oracle, pyref):
+    """oracle_field_op_batch (the CPU side of the device's primitive-parity ABI) against the structurally different pure-
+    Python model: Fp / Fp2 by integer arithmetic, Fp12 by the dense degree-6 polynomial model.  The reference has no Fp6 /
+    Fp12 vectors, so these two agreeing is what the GPU fuzz tests lean on."""
+    B, P = pyref, pyref.P
+    rnd = random.Random(77)
+    n = 24
+    a, av = _rand_fp_bytes(rnd, n, P)
+    b, bv = _rand_fp_bytes(random.Random(78), n, P)
+    i2b = lambda vs: b"".join(v.to_bytes(32, "big") for v in vs)
+    assert oracle.field_op_batch(0, a, b, n) == i2b([x * y % P for x, y in zip(av, bv)])
+    assert oracle.field_op_batch(1, a, None, n) == i2b([x * x % P for x in av])
+    assert oracle.field_op_batch(2, a, None, n) == i2b([pow(x, P - 2, P) for x in av])
+    assert oracle.field_op_batch(3, a, b, n) == i2b([(x + y) % P for x, y in zip(av, bv)])
+    assert oracle.field_op_batch(4, a, b, n) == i2b([(x - y) % P for x, y in zip(av, bv)])
+    assert oracle.field_op_batch(5, a, None, n) == i2b([(-x) % P for x in av])
+    assert oracle.field_op_batch(8, a, None, n) == i2b([9 * x % P for x in av])
+    sq = oracle.field_op_batch(6, a, None, n); isq = oracle.field_op_batch(7, a, None, n)
+    for k, x in enumerate(av):
+        is_sq = x == 0 or pow(x, (P - 1) // 2, P) == 1
+        assert int.from_bytes(isq[32 * k:32 * k + 32], "big") == (1 if is_sq else 0)
+        r = int.from_bytes(sq[32 * k:32 * k + 32], "big")
+        assert (r * r % P == x) if is_sq else r == 0
+    # Fp2: elements are c0 || c1
+    a2 = a + b; n2 = n                      # pair (av[k], bv[k])?  build explicitly
+    xs = [(rnd.randrange(P), rnd.randrange(P)) for _ in range(n2)]
+    ys = [(rnd.randrange(P), rnd.randrange(P)) for _ in range(n2)]
+    xs[0] = (0, 0); xs[1] = (1, 0); xs[2] = (0, 1); ys[3] = (P - 1, P - 1)
+    f2b = lambda vs: b"".join(c0.to_bytes(32, "big") + c1.to_bytes(32, "big") for c0, c1 in vs)
+    assert oracle.field_op_batch(16, f2b(xs), f2b(ys), n2) == f2b([B.f2_mul(x, y) for x, y in zip(xs, ys)])
+    assert oracle.field_op_batch(17, f2b(xs), None, n2) == f2b([B.f2_sqr(x) for x in xs])
+    assert oracle.field_op_batch(18, f2b(xs[1:]), None, n2 - 1) == f2b([B.f2_inv(x) for x in xs[1:]])
+    assert oracle.field_op_batch(19, f2b(xs), None, n2) == f2b([B.f2_mul(x, B.XI) for x in xs])
+    assert oracle.field_op_batch(20, f2b(xs), None, n2) == f2b([B.f2_conj(x) for x in xs])
+    rt = oracle.field_op_batch(21, f2b(xs), None, n2)
+    for k, x in enumerate(xs):
+        r = (int.from_bytes(rt[64 * k:64 * k + 32], "big"), int.from_bytes(rt[64 * k + 32:64 * k + 64], "big"))
+        assert B.f2_sqr(r) == x if B.f2_is_square(x) else r == (0, 0)
+    # Fp12 through the Gt byte layout
+    m = 10
+    fa = [[(rnd.randrange(P), rnd.randrange(P)) for _ in range(6)] for _ in range(m)]
+    fb = [[(rnd.randrange(P), rnd.randrange(P)) for _ in range(6)] for _ in range(m)]
+    fa[0] = [(1, 0)] + [(0, 0)] * 5
+    A12 = b"".join(B.f12_to_bytes(x) for x in fa); B12 = b"".join(B.f12_to_bytes(x) for x in fb)
+    j = lambda xs_: b"".join(B.f12_to_bytes(x) for x in xs_)
+    assert oracle.field_op_batch(48, A12, B12, m) == j([B.f12_mul(x, y) for x, y in zip(fa, fb)])
+    assert oracle.field_op_batch(49, A12, None, m) == j([B.f12_sqr(x) for x in fa])
+    assert oracle.field_op_batch(50, A12, None, m) == j([B.f12_inv(x) for x in fa])
+    assert oracle.field_op_batch(51, A12, None, m) == j([B.f12_conj(x) for x in fa])
+    for k in (1, 2, 3):
+        assert oracle.field_op_batch(51 + k, A12, None, m) == j([B.f12_frob(x, k) for x in fa])
+    # sparse product: only the 0 / 3 / 4 slots (w^0, w^1, w^3 in the model's w-power indexing) of b are used
+    sparse = []
+    for y in fb:
+        full = B.f12_from_bytes(B.f12_to_bytes(y))
+        keep = B.f12_from_bytes(B.f12_to_bytes(y)[:64] + bytes(128) + B.f12_to_bytes(y)[192:320] + bytes(64))
+        sparse.append(keep)
+    assert oracle.field_op_batch(56, A12, B12, m) == j([B.f12_mul(x, y) for x, y in zip(fa, sparse)])
+    # Fp6 via Fp12 with c1 = 0: (a0, 0) * (b0, 0) = (a0 b0, 0)
+    six = lambda x: B.f12_to_bytes(x)[:192]
+    a6 = b"".join(six(x) for x in fa); b6 = b"".join(six(x) for x in fb)
+    emb = lambda s6: b"".join(s6[192 * k:192 * k + 192] + bytes(192) for k in range(m))
+    prod = oracle.field_op_batch(32, a6, b6, m)
+    assert emb(prod) == oracle.field_op_batch(48, emb(a6), emb(b6), m)
+    assert oracle.field_op_batch(33, a6, None, m) == oracle.field_op_batch(32, a6, a6, m)
+    inv6 = oracle.field_op_batch(34, a6, None, m)
+    one6 = (1).to_bytes(32, "big") + bytes(160)
+    assert oracle.field_op_batch(32, a6, inv6, m) == one6 * m
+    # cyclotomic squaring == squaring on cyclotomic elements (easy part of the final exponentiation output)
+    g = oracle.pairing_batch(oracle.g1_generator(), oracle.g2_generator(), 1)
+    assert oracle.field_op_batch(55, g, None, 1) == oracle.field_op_batch(49, g, None, 1)
