@@ -40,6 +40,7 @@ struct blsbn254_ctx {
   DevBuf fe[6];          // final-exponentiation phase buffers (x, a, b, c, b2, d), 108 x n limbs each
   DevBuf rlc_a2, rlc_a, rlc_b, rlc_elig, rlc_f2, rlc_bytes, rlc_neg, rlc_ok, rlc_idx, rlc_cpk, rlc_csig, rlc_ch, rlc_csub, rlc_cbm;   // RLC batch verification
   DevBuf status_all;     // per-element decode status of a chunked call, all chunks
+  DevBuf th_x, th_num, th_den, th_glv, th_part, th_part2;   // threshold combine: ids, partial products, GLV halves, window sums
   DevBuf fe_slots;       // the ten named powers of the t -> t^x addition chain, 10 x 108 x n limbs
   uint8_t dst_host[256];  // the (pre-hashed if oversize) DST currently resident in `dst`, and its length; -1 = none
   int dst_host_len = -1;
@@ -120,6 +121,7 @@ void blsbn254_ctx_destroy(blsbn254_ctx* c) {
   for (DevBuf* b : bufs) b->release();
   for (DevBuf& b : c->fe) b.release();
   c->fe_slots.release();
+  { DevBuf* tb[] = {&c->th_x, &c->th_num, &c->th_den, &c->th_glv, &c->th_part, &c->th_part2}; for (DevBuf* b : tb) b->release(); }
   { DevBuf* rb[] = {&c->rlc_a2, &c->rlc_a, &c->rlc_b, &c->rlc_elig, &c->rlc_f2, &c->rlc_bytes, &c->rlc_neg, &c->rlc_ok, &c->rlc_idx, &c->rlc_cpk, &c->rlc_csig, &c->rlc_ch, &c->rlc_csub, &c->rlc_cbm};
     for (DevBuf* b : rb) b->release(); }
   (void)hipStreamDestroy(c->stream);
@@ -700,29 +702,97 @@ int blsbn254_aggregate_sigs(blsbn254_ctx* c, const uint8_t* sigs, size_t n, uint
   HIPCHK(c, hipSetDevice(c->device));
   HIPCHK(c, c->in_a.reserve(64 * n)); HIPCHK(c, c->h_ws.reserve(n * 27 * 4)); HIPCHK(c, c->status.reserve(n));
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, sigs, 64 * n, hipMemcpyHostToDevice, c->stream));
-  LAUNCH(c, "g1_load", k_g1_load, n, (const uint8_t*)c->in_a.p, (const uint8_t*)nullptr, n, (int32_t*)c->h_ws.p, (uint8_t*)c->status.p);
+  LAUNCH(c, "g1_load", k_g1_load, n, (const uint8_t*)c->in_a.p, n, (int32_t*)c->h_ws.p, (uint8_t*)c->status.p);
   int bad; int rc = first_bad(c, (const uint8_t*)c->status.p, n, 1, 1, &bad);
   if (rc) return rc;
   if (bad >= 0) return BLSBN254_ERR_G1;
   return g1_sum_to_bytes(c, n, out);
 }
+// Threshold combine (k_threshold.hip): Lagrange coefficients over t x sqrt(t) lanes, GLV-split 4-bit-window MSM over
+// 2t x 32 lanes with in-workgroup sums, one short finishing kernel.  One host synchronisation at the end.
 int blsbn254_threshold_combine(blsbn254_ctx* c, const uint8_t* ids, const uint8_t* partial_sigs, size_t t, uint8_t out_sig[64]) {
   if (!c || !out_sig || (t && (!ids || !partial_sigs))) return BLSBN254_E_ARG;
   if (t == 0) { std::memset(out_sig, 0, 64); out_sig[63] = 1; return 0; }
+  CHECK_LANES(c, t);
   HIPCHK(c, hipSetDevice(c->device));
+  size_t S = 1;
+  while (S < 64 && S * S < t) ++S;                       // ~sqrt(t) slices: t x S lanes, critical path 2 (t / S + S) products
+  const size_t J = (t + S - 1) / S;
+  size_t n_chunks = (2 * t + 255) / 256;
   HIPCHK(c, c->in_a.reserve(64 * t)); HIPCHK(c, c->in_b.reserve(32 * t)); HIPCHK(c, c->scalars.reserve(32 * t));
-  HIPCHK(c, c->h_ws.reserve(t * 27 * 4)); HIPCHK(c, c->status.reserve(t));
+  HIPCHK(c, c->status.reserve(2 * t)); HIPCHK(c, c->flags.reserve(t)); HIPCHK(c, c->misc.reserve(64)); HIPCHK(c, c->out.reserve(64));
+  HIPCHK(c, c->th_x.reserve(9 * t * 4)); HIPCHK(c, c->th_num.reserve(9 * t * S * 4)); HIPCHK(c, c->th_den.reserve(9 * t * S * 4));
+  HIPCHK(c, c->th_glv.reserve(9 * t * 4)); HIPCHK(c, c->th_part.reserve(27 * 32 * n_chunks * 4)); HIPCHK(c, c->th_part2.reserve(27 * 32 * ((n_chunks + 1) / 2) * 4));
+  uint8_t* st_ids = (uint8_t*)c->status.p; uint8_t* st_pts = st_ids + t; uint8_t* dup = (uint8_t*)c->flags.p;
+  int* d_bad = (int*)c->misc.p;
+  static const int init[2] = {0x7fffffff, 0x7fffffff};      // static: outlives the asynchronous copy
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, partial_sigs, 64 * t, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->in_b.p, ids, 32 * t, hipMemcpyHostToDevice, c->stream));
-  LAUNCH(c, "lagrange", k_lagrange, t, (const uint8_t*)c->in_b.p, t, (uint8_t*)c->scalars.p, (uint8_t*)c->status.p);
-  int bad; int rc = first_bad(c, (const uint8_t*)c->status.p, t, 1, 1, &bad);
-  if (rc) return rc;
-  if (bad >= 0) return BLSBN254_ERR_SCALAR;
-  LAUNCH(c, "g1_load_mul", k_g1_load, t, (const uint8_t*)c->in_a.p, (const uint8_t*)c->scalars.p, t, (int32_t*)c->h_ws.p, (uint8_t*)c->status.p);
-  rc = first_bad(c, (const uint8_t*)c->status.p, t, 1, 1, &bad);
-  if (rc) return rc;
-  if (bad >= 0) return BLSBN254_ERR_G1;
-  return g1_sum_to_bytes(c, t, out_sig);
+  HIPCHK(c, hipMemcpyAsync(d_bad, init, 8, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(dup, 0, t, c->stream));
+  LAUNCH(c, "fr_decode", k_fr_decode, t, (const uint8_t*)c->in_b.p, t, (int32_t*)c->th_x.p, st_ids);
+  { ProfScope ps_(c, "lagrange_partial");
+    hipLaunchKernelGGL(k_lagrange_partial, dim3(nblocks(t), (unsigned)S), dim3(256), 0, c->stream, (const int32_t*)c->th_x.p, t, J,
+                       (int32_t*)c->th_num.p, (int32_t*)c->th_den.p, dup); }
+  HIPCHK(c, hipGetLastError());
+  LAUNCH(c, "lagrange_finish", k_lagrange_finish, t, (const int32_t*)c->th_num.p, (const int32_t*)c->th_den.p, t, S, (uint8_t*)c->scalars.p, (uint32_t*)c->th_glv.p);
+  { ProfScope ps_(c, "msm_window");
+    hipLaunchKernelGGL(k_msm_window, dim3((unsigned)n_chunks, 32), dim3(256), 0, c->stream, (const uint8_t*)c->in_a.p, (const uint32_t*)c->th_glv.p, t,
+                       (int32_t*)c->th_part.p, st_pts); }
+  HIPCHK(c, hipGetLastError());
+  int32_t* pa = (int32_t*)c->th_part.p; int32_t* pb = (int32_t*)c->th_part2.p;
+  while (n_chunks > 16) {                                  // large t only: fold the chunk axis pairwise
+    const size_t no = (n_chunks + 1) / 2;
+    LAUNCH(c, "msm_fold", k_msm_fold, no * 32, (const int32_t*)pa, n_chunks, pb);
+    std::swap(pa, pb); n_chunks = no;
+  }
+  { ProfScope ps_(c, "msm_finish");
+    hipLaunchKernelGGL(k_msm_finish, dim3(1), dim3(64), 0, c->stream, (const int32_t*)pa, n_chunks, (uint8_t*)c->out.p); }
+  HIPCHK(c, hipGetLastError());
+  // ids: decoded, non-zero (status 1) and pairwise distinct (dup 0); points: decoded
+  LAUNCH(c, "status_reduce", k_status_reduce, t, (const uint8_t*)st_ids, t, (uint8_t)1, (uint8_t)1, d_bad);
+  LAUNCH(c, "status_reduce", k_status_reduce, t, (const uint8_t*)dup, t, (uint8_t)1, (uint8_t)0, d_bad);
+  LAUNCH(c, "status_reduce", k_status_reduce, t, (const uint8_t*)st_pts, t, (uint8_t)1, (uint8_t)1, d_bad + 1);
+  int bad[2];
+  HIPCHK(c, hipMemcpyAsync(bad, d_bad, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(out_sig, c->out.p, 64, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (bad[0] != 0x7fffffff) return BLSBN254_ERR_SCALAR;
+  if (bad[1] != 0x7fffffff) return BLSBN254_ERR_G1;
+  return 0;
+}
+// The Lagrange coefficients at zero alone (t x 32 bytes big-endian), for callers that combine elsewhere and for tests.
+int blsbn254_lagrange_at_zero(blsbn254_ctx* c, const uint8_t* ids, size_t t, uint8_t* out) {
+  if (!c || (t && (!ids || !out))) return BLSBN254_E_ARG;
+  if (t == 0) return 0;
+  CHECK_LANES(c, t);
+  HIPCHK(c, hipSetDevice(c->device));
+  size_t S = 1;
+  while (S < 64 && S * S < t) ++S;
+  const size_t J = (t + S - 1) / S;
+  HIPCHK(c, c->in_b.reserve(32 * t)); HIPCHK(c, c->scalars.reserve(32 * t)); HIPCHK(c, c->status.reserve(t)); HIPCHK(c, c->flags.reserve(t));
+  HIPCHK(c, c->misc.reserve(64));
+  HIPCHK(c, c->th_x.reserve(9 * t * 4)); HIPCHK(c, c->th_num.reserve(9 * t * S * 4)); HIPCHK(c, c->th_den.reserve(9 * t * S * 4)); HIPCHK(c, c->th_glv.reserve(9 * t * 4));
+  uint8_t* st_ids = (uint8_t*)c->status.p; uint8_t* dup = (uint8_t*)c->flags.p;
+  int* d_bad = (int*)c->misc.p;
+  const int init = 0x7fffffff;
+  HIPCHK(c, hipMemcpyAsync(c->in_b.p, ids, 32 * t, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_bad, &init, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(dup, 0, t, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));             // `init` is on the stack
+  LAUNCH(c, "fr_decode", k_fr_decode, t, (const uint8_t*)c->in_b.p, t, (int32_t*)c->th_x.p, st_ids);
+  { ProfScope ps_(c, "lagrange_partial");
+    hipLaunchKernelGGL(k_lagrange_partial, dim3(nblocks(t), (unsigned)S), dim3(256), 0, c->stream, (const int32_t*)c->th_x.p, t, J,
+                       (int32_t*)c->th_num.p, (int32_t*)c->th_den.p, dup); }
+  HIPCHK(c, hipGetLastError());
+  LAUNCH(c, "lagrange_finish", k_lagrange_finish, t, (const int32_t*)c->th_num.p, (const int32_t*)c->th_den.p, t, S, (uint8_t*)c->scalars.p, (uint32_t*)c->th_glv.p);
+  LAUNCH(c, "status_reduce", k_status_reduce, t, (const uint8_t*)st_ids, t, (uint8_t)1, (uint8_t)1, d_bad);
+  LAUNCH(c, "status_reduce", k_status_reduce, t, (const uint8_t*)dup, t, (uint8_t)1, (uint8_t)0, d_bad);
+  int bad;
+  HIPCHK(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(out, c->scalars.p, 32 * t, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return bad != 0x7fffffff ? BLSBN254_ERR_SCALAR : 0;
 }
 
 // ---------------- field / tower primitives (debug ABI) and Gt group operations

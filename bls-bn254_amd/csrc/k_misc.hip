@@ -1,7 +1,6 @@
 // k_misc.hip -- hash-to-curve, point checks, product / sum trees, Lagrange coefficients, reductions,
 // and the VALU roofline probe.
 #include "lane_ops.h"
-#include "fr29.h"
 #include "kernels.h"
 using namespace bn;
 
@@ -44,22 +43,12 @@ BN_KERNEL k_fp12_mul_pairs(const int32_t* in, size_t n_in, size_t in_stride, int
   if (2 * i + 1 < n_in) a = fp12_mul(a, fp12_load_limbs(in + 2 * i + 1, in_stride));
   fp12_store_limbs(out + i, out_stride, a);
 }
-BN_KERNEL k_g1_load(const uint8_t* g1, const uint8_t* scalars, size_t n, int32_t* ws, uint8_t* status) {
+BN_KERNEL k_g1_load(const uint8_t* g1, size_t n, int32_t* ws, uint8_t* status) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   bool ok;
   G1A a = g1_decode(g1 + 64 * i, ok);
-  G1P p = proj_from_affine(a);
-  if (scalars) {
-    uint64_t k[4];
-    for (int w = 0; w < 4; ++w) {
-      uint64_t v = 0;
-      for (int j = 0; j < 8; ++j) v = (v << 8) | scalars[32 * i + 8 * (3 - w) + j];
-      k[w] = v;
-    }
-    p = proj_mul_256(p, k);
-  }
-  store_g1p(ws + i, n, p);
+  store_g1p(ws + i, n, proj_from_affine(a));
   status[i] = ok ? 1 : 0;
 }
 BN_KERNEL k_g1_add_pairs(const int32_t* in, size_t n_in, size_t in_stride, int32_t* out, size_t out_stride) {
@@ -73,14 +62,6 @@ BN_KERNEL k_g1_add_pairs(const int32_t* in, size_t n_in, size_t in_stride, int32
 BN_KERNEL k_g1_to_bytes(const int32_t* ws, size_t stride, uint8_t* out) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   g1_encode(out, g1_to_affine(load_g1p(ws, stride)));
-}
-BN_KERNEL k_lagrange(const uint8_t* ids, size_t t, uint8_t* scalars, uint8_t* status) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= t) return;
-  bool ok;
-  Fr lam = lagrange_at_zero(ids, t, i, ok);
-  fr_to_be(scalars + 32 * i, lam);
-  status[i] = ok ? 1 : 0;
 }
 // compressed codecs: mode 0 compress (uncompressed in -> compressed out), 1 decompress; status 1 = ok
 BN_KERNEL k_g1_codec(const uint8_t* in, size_t n, uint8_t* out, uint8_t* status, int mode) {

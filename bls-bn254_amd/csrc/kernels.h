@@ -39,7 +39,7 @@ BN_KERNEL k_fe_h3(const int32_t* t, const int32_t* a, const int32_t* c, const in
 BN_KERNEL k_fp12_from_bytes(const uint8_t* in, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status);
 BN_KERNEL k_fp12_to_bytes(const int32_t* f_ws, size_t n, size_t stride, uint8_t* out);
 BN_KERNEL k_fp12_mul_pairs(const int32_t* in, size_t n_in, size_t in_stride, int32_t* out, size_t out_stride);
-BN_KERNEL k_g1_load(const uint8_t* g1, const uint8_t* scalars, size_t n, int32_t* ws, uint8_t* status);
+BN_KERNEL k_g1_load(const uint8_t* g1, size_t n, int32_t* ws, uint8_t* status);
 BN_KERNEL k_g1_add_pairs(const int32_t* in, size_t n_in, size_t in_stride, int32_t* out, size_t out_stride);
 BN_KERNEL k_g1_to_bytes(const int32_t* ws, size_t stride, uint8_t* out);
 BN_KERNEL k_sign(const uint8_t* sks, const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
@@ -60,7 +60,12 @@ BN_KERNEL k_rlc_gather(const uint32_t* idx, size_t m, const uint8_t* pks, const 
                        const uint8_t* sub_ok, uint8_t* c_pks, uint8_t* c_sigs, int32_t* c_h, uint8_t* c_sub);
 BN_KERNEL k_field_op(int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status);
 BN_KERNEL k_gt_pow(const uint8_t* gt, const uint8_t* scalars, size_t n, uint8_t* out, uint8_t* status);
-BN_KERNEL k_lagrange(const uint8_t* ids, size_t t, uint8_t* scalars, uint8_t* status);
+BN_KERNEL k_fr_decode(const uint8_t* ids, size_t t, int32_t* x_ws, uint8_t* status);
+BN_KERNEL k_lagrange_partial(const int32_t* x_ws, size_t t, size_t J, int32_t* pnum, int32_t* pden, uint8_t* dup);
+BN_KERNEL k_lagrange_finish(const int32_t* pnum, const int32_t* pden, size_t t, size_t S, uint8_t* scalars, uint32_t* glv_ws);
+BN_KERNEL k_msm_window(const uint8_t* g1, const uint32_t* glv_ws, size_t t, int32_t* part, uint8_t* status);
+__global__ void __launch_bounds__(64) k_msm_finish(const int32_t* part, size_t n_chunks, uint8_t* out);
+BN_KERNEL k_msm_fold(const int32_t* in, size_t n_in, int32_t* out);
 __global__ void __launch_bounds__(256) k_valu_peak(uint32_t* out, uint32_t seed, int iters, int kind, uint64_t* stamps);
 __global__ void k_status_reduce(const uint8_t* status, size_t n, uint8_t want_mask, uint8_t want_val, int* first_bad);
 __global__ void k_and_reduce(const uint8_t* flags, const uint8_t* sub_ok, size_t n, int* all_ok);

@@ -243,6 +243,12 @@ class Engine:
         self._chk(self._lib.blsbn254_threshold_combine(self._ctx, pa, ps, ctypes.c_size_t(t), po))
         return o.tobytes()
 
+    def lagrange_at_zero(self, ids, t):
+        """t x 32 bytes: lambda_i = prod_{j != i} x_j / (x_j - x_i) (big-endian Fr)."""
+        a, pa = _inbuf(ids, 32 * t); o, po = _outbuf(32 * t)
+        self._chk(self._lib.blsbn254_lagrange_at_zero(self._ctx, pa, ctypes.c_size_t(t), po))
+        return o[:32 * t].tobytes()
+
     # ---- Gt group operations and the field-primitive debug ABI
     FIELD_OP_WIDTH = {**{k: 32 for k in range(0, 9)}, **{k: 64 for k in range(16, 22)}, **{k: 192 for k in range(32, 36)},
                       **{k: 384 for k in range(48, 57)}}

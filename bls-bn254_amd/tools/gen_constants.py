@@ -243,6 +243,17 @@ def main():
     s.append("BN_CONST int32_t FR_R2[9] = %s;    // R^2 mod r\n" % fmt_limbs(limbs(MONT_R * MONT_R % RR)))
     s.append("BN_CONST int32_t FR_R3[9] = %s;    // R^3 mod r\n" % fmt_limbs(limbs(pow(MONT_R, 3, RR))))
     s.append("BN_CONST uint64_t EXP_RM2[4] = %s;       // r-2\n" % words(RR - 2))
+    # GLV endomorphism of G1 (threshold MSM): phi(x, y) = (beta x, y) = [lambda](x, y); short lattice basis of
+    # {(a, b): a + b lambda = 0 mod r} by the extended Euclidean algorithm; rounding constants scaled by 2^256
+    glv = glv_constants()
+    s.append(fp_c("GLV_BETA", glv["beta"]))
+    w8 = lambda v: "{" + ", ".join("0x%08xu" % ((v >> (32 * i)) & 0xffffffff) for i in range(8)) + "}"
+    for name in ("A1", "B1", "A2", "B2"):
+        s.append("BN_CONST uint32_t GLV_%s[8] = %s;   // basis entry %s as a 256-bit two's-complement number (%d)\n" % (name, w8(glv[name.lower()] % (1 << 256)), name.lower(), glv[name.lower()]))
+    for name in ("G1", "G2"):
+        s.append("BN_CONST uint32_t GLV_%s[8] = %s;   // |%s| = floor(2^256 |%s| / r): c = (k * G) >> 256\n" % (name, w8(glv[name.lower()]), "c1" if name == "G1" else "c2", "b2" if name == "G1" else "b1"))
+    s.append("BN_CONST bool GLV_C1_NEG = %s, GLV_C2_NEG = %s;   // signs of c1 = round(b2 k / r), c2 = round(-b1 k / r)\n" % ("true" if glv["c1_neg"] else "false", "true" if glv["c2_neg"] else "false"))
+    s.append("BN_CONST uint64_t GLV_LAMBDA[4] = %s;   // the eigenvalue (documentation / tests)\n" % words(glv["lam"]))
     s.append("}  // namespace bnc\n\n")
     # fixed-Q line table for -G2gen (the verify equation pairs the signature with -G2gen)
     negG2 = (G2X, f2neg(G2Y))
@@ -263,6 +274,87 @@ def main():
     with open(out, "w") as f:
         f.write("".join(s))
     print("wrote", os.path.normpath(out), "(%d line entries)" % len(tab))
+
+
+def g1_mul_affine(pt, k):
+    """affine double-and-add on y^2 = x^3 + 3 (generator-time check of the endomorphism only)"""
+    def add(a, b):
+        if a is None: return b
+        if b is None: return a
+        if a[0] == b[0]:
+            if (a[1] + b[1]) % P == 0: return None
+            l = 3 * a[0] * a[0] * inv(2 * a[1]) % P
+        else:
+            l = (b[1] - a[1]) * inv((b[0] - a[0]) % P) % P
+        x = (l * l - a[0] - b[0]) % P
+        return (x, (l * (a[0] - x) - a[1]) % P)
+    acc = None
+    for bit in bin(k)[2:]:
+        acc = add(acc, acc)
+        if bit == '1':
+            acc = add(acc, pt)
+    return acc
+
+
+def glv_split_words(k, c):
+    """The device algorithm (glv.h) restated on Python integers, word-exact: returns (k1, k2) as signed integers."""
+    M = 1 << 256
+    c1 = (k * c["g1"]) >> 256
+    c2 = (k * c["g2"]) >> 256
+    C1 = (-c1 if c["c1_neg"] else c1) % M
+    C2 = (-c2 if c["c2_neg"] else c2) % M
+    k1 = (k - C1 * (c["a1"] % M) - C2 * (c["a2"] % M)) % M
+    k2 = (-(C1 * (c["b1"] % M) + C2 * (c["b2"] % M))) % M
+    sgn = lambda v: v - M if v >> 255 else v
+    return sgn(k1), sgn(k2)
+
+
+def glv_constants():
+    import math
+    import random
+    # a primitive cube root of unity mod r and mod p; pick the pair with phi = [lambda]
+    def cube_root_of_unity(m):
+        g = 2
+        while True:
+            c = pow(g, (m - 1) // 3, m)
+            if c != 1:
+                return c
+            g += 1
+    lam = cube_root_of_unity(RR)
+    beta = cube_root_of_unity(P)
+    G = (1, 2)
+    Q = g1_mul_affine(G, lam)
+    if Q != (beta * G[0] % P, G[1]):
+        beta = beta * beta % P
+    assert Q == (beta * G[0] % P, G[1])
+    # extended Euclid on (r, lambda): rows (rem, t) with rem = s r + t lambda
+    rows = [(RR, 0), (lam, 1)]
+    sq = math.isqrt(RR)
+    while rows[-1][0] >= sq:
+        q = rows[-2][0] // rows[-1][0]
+        rows.append((rows[-2][0] - q * rows[-1][0], rows[-2][1] - q * rows[-1][1]))
+    q = rows[-2][0] // rows[-1][0]
+    nxt = (rows[-2][0] - q * rows[-1][0], rows[-2][1] - q * rows[-1][1])
+    v1 = (rows[-1][0], -rows[-1][1])
+    cands = [(rows[-2][0], -rows[-2][1]), (nxt[0], -nxt[1])]
+    v2 = min(cands, key=lambda v: v[0] * v[0] + v[1] * v[1])
+    a1, b1 = v1
+    a2, b2 = v2
+    det = a1 * b2 - a2 * b1
+    assert abs(det) == RR and (a1 + b1 * lam) % RR == 0 and (a2 + b2 * lam) % RR == 0
+    # c1 = round(b2 k / det), c2 = round(-b1 k / det); on the device: magnitude (k * g) >> 256, sign separate
+    n1, n2 = b2 * (1 if det > 0 else -1), -b1 * (1 if det > 0 else -1)
+    c = {"lam": lam, "beta": beta, "a1": a1, "b1": b1, "a2": a2, "b2": b2,
+         "g1": (abs(n1) << 256) // RR, "g2": (abs(n2) << 256) // RR, "c1_neg": n1 < 0, "c2_neg": n2 < 0}
+    # the truncated quotients are off by at most one: the halves must still fit 128 bits with room to spare
+    rnd = random.Random(7)
+    worst = 0
+    for k in [0, 1, 2, RR - 1, RR - 2, lam, RR - lam, (RR - 1) // 2] + [rnd.randrange(RR) for _ in range(20000)]:
+        k1, k2 = glv_split_words(k, c)
+        assert (k1 + k2 * lam - k) % RR == 0
+        worst = max(worst, abs(k1).bit_length(), abs(k2).bit_length())
+    assert worst <= 127, worst
+    return c
 
 
 if __name__ == "__main__":

@@ -125,6 +125,9 @@ int blsbn254_aggregate_sigs(blsbn254_ctx* ctx, const uint8_t* sigs, size_t n, ui
 /* sum_i lambda_i * sig_i with Lagrange coefficients at 0 for the t distinct non-zero ids
  * (Mul<Scalar> g1.rs:518-534 + Sum; Fr arithmetic scalar.rs:523-548) */
 int blsbn254_threshold_combine(blsbn254_ctx* ctx, const uint8_t* ids, const uint8_t* partial_sigs, size_t t, uint8_t out_sig[64]);
+/* The Lagrange coefficients alone: out[i] = prod_{j != i} x_j / (x_j - x_i) as 32 bytes big-endian (Scalar mul / invert,
+ * scalar.rs:523-548, :216-219).  ids that do not decode (>= r), are zero or repeat return BLSBN254_ERR_SCALAR. */
+int blsbn254_lagrange_at_zero(blsbn254_ctx* ctx, const uint8_t* ids, size_t t, uint8_t* out /* t*32 */);
 
 /* ---- signing side (also used to generate large synthetic batches) ----------- */
 /* sig_i = [sk_i] H(msg_i): G1Projective::hash (g1.rs:910-919) + Mul<Scalar> (g1.rs:518-534, :821-841).

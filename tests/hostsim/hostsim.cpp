@@ -7,6 +7,7 @@
 #define BN_LINE_TABLE_QUAL static const
 #include "../../bls-bn254_amd/csrc/lane_ops.h"
 #include "../../bls-bn254_amd/csrc/keygen.h"
+#include "../../bls-bn254_amd/csrc/glv.h"
 #include <cstring>
 
 using namespace bn;
@@ -181,6 +182,20 @@ int hs_g2_codec_roundtrip(const uint8_t* g2, uint8_t* comp64, uint8_t* back128) 
   G2A q = g2_decompress(comp64, ok2);
   g2_encode(back128, q);
   return ok && ok2;
+}
+// GLV split of a canonical scalar (32 B big-endian): out = |k1| (16 B BE) || |k2| (16 B BE), returns sign bits (1: k1 < 0, 2: k2 < 0)
+int hs_glv_split(const uint8_t* k_be, uint8_t* out32) {
+  uint32_t w[8];
+  for (int j = 0; j < 8; ++j) w[j] = load_be32(k_be + 4 * (7 - j));
+  GlvSplit g = glv_split(w);
+  for (int j = 0; j < 4; ++j) { store_be32(out32 + 4 * (3 - j), g.k1[j]); store_be32(out32 + 16 + 4 * (3 - j), g.k2[j]); }
+  return (g.neg1 ? 1 : 0) | (g.neg2 ? 2 : 0);
+}
+// the endomorphism itself on an affine G1 point: (beta x, y)
+void hs_glv_phi(const uint8_t* g1, uint8_t* out64) {
+  bool ok; G1A p = g1_decode(g1, ok);
+  p.x = fp_mul(p.x, fp_const(bnc::GLV_BETA));
+  g1_encode(out64, p);
 }
 void hs_stats(double* out) {
   CheckStats& s = check_stats();

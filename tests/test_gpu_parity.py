@@ -537,3 +537,45 @@ def test_gt_group_ops(eng, oracle, pyref):
     # bilinearity through the new entry points: e(aP, Q) = e(P, Q)^a
     a = rnd.randrange(1, pyref.R)
     assert eng.pairing_batch(oracle.g1_mul(G1, a), G2, 1) == eng.gt_pow_batch(eng.pairing_batch(G1, G2, 1), a.to_bytes(32, "big"), 1)
+
+
+@pytest.mark.parametrize("t", [1, 2, 3, 63, 64, 65, 257, 1000, 5000])
+def test_threshold_combine_sizes_and_lagrange(eng, oracle, pyref, M, t):
+    """The chip-filling threshold path (Lagrange over t x sqrt(t) lanes, GLV-split windowed MSM) against the oracle's
+    t x 255-step ladders: same bytes, for sizes that exercise one lane, partial waves, several chunks and the chunk fold
+    (t = 5000: 40 chunks).  Random 254-bit ids (not small integers) and random points incl. the identity and repeats."""
+    rnd = random.Random(100 + t)
+    R = pyref.R
+    ids = rnd.sample(range(1, 1 << 20), t) if t > 300 else [rnd.randrange(1, R) for _ in range(t)]
+    idb = b"".join(i.to_bytes(32, "big") for i in ids)
+    G1 = oracle.g1_generator()
+    pool = [oracle.g1_mul(G1, rnd.randrange(1, R)) for _ in range(min(t, 24))] + [IDENT1]
+    parts = b"".join(pool[rnd.randrange(len(pool))] for _ in range(t))
+    lam = eng.lagrange_at_zero(idb, t)
+    if t <= 1000:
+        assert lam == oracle.fr_lagrange_at_zero(idb, t)
+    else:       # O(t^2) on the CPU: spot-check 40 coefficients with Python integers
+        for i in rnd.sample(range(t), 40):
+            num = den = 1
+            for j in range(t):
+                if j != i:
+                    num = num * ids[j] % R; den = den * (ids[j] - ids[i]) % R
+            assert int.from_bytes(lam[32 * i:32 * i + 32], "big") == num * pow(den, R - 2, R) % R
+    got = eng.threshold_combine(idb, parts, t)
+    if t <= 1000:
+        assert got == oracle.threshold_combine(idb, parts, t)
+    else:       # sum_i lambda_i sigma_i with the coefficients already checked: group the equal points
+        acc = {}
+        for i in range(t):
+            p = parts[64 * i:64 * i + 64]
+            acc[p] = (acc.get(p, 0) + int.from_bytes(lam[32 * i:32 * i + 32], "big")) % R
+        want = IDENT1
+        for p, k in acc.items():
+            if p != IDENT1 and k:
+                want = oracle.g1_add(want, oracle.g1_mul(p, k))
+        assert got == want
+    if t >= 3:
+        with pytest.raises(M.InvalidScalarBytes):
+            eng.threshold_combine(idb[:32 * (t - 1)] + idb[:32], parts, t)              # last id repeats the first
+        with pytest.raises(M.InvalidG1Bytes):
+            eng.threshold_combine(idb, parts[:64 * (t - 1)] + b"\xff" * 64, t)          # undecodable partial signature

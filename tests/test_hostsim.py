@@ -167,3 +167,24 @@ def test_is_square_by_jacobi_symbol(hs, pyref):
     vals += [v * v % P for v in vals[:40]]
     for v in vals:
         assert hs.hs_fp_is_square(b32(v)) == (1 if pow(v, (P - 1) // 2, P) in (0, 1) else 0), v
+
+
+def test_glv_split_and_endomorphism(hs, oracle, pyref):
+    """glv.h on the host: k = k1 + k2 lambda (mod r) with both halves below 2^127, and phi(P) = (beta x, y) = [lambda] P
+    (the decomposition the threshold MSM runs on the device)."""
+    R = pyref.R
+    lam = 0xb3c4d79d41a917585bfc41088d8daaa78b17ea66b99c90dd
+    assert (lam * lam + lam + 1) % R == 0
+    rnd = random.Random(9)
+    out = ctypes.create_string_buffer(32)
+    for k in [0, 1, 2, R - 1, R - 2, lam, R - lam, (R - 1) // 2, 1 << 253] + [rnd.randrange(R) for _ in range(3000)]:
+        sg = hs.hs_glv_split(b32(k), out)
+        k1 = int.from_bytes(out.raw[:16], "big") * (-1 if sg & 1 else 1)
+        k2 = int.from_bytes(out.raw[16:], "big") * (-1 if sg & 2 else 1)
+        assert (k1 + k2 * lam - k) % R == 0 and abs(k1) < (1 << 127) and abs(k2) < (1 << 127), hex(k)
+    G1 = oracle.g1_generator()
+    o64 = ctypes.create_string_buffer(64)
+    for _ in range(4):
+        p = oracle.g1_mul(G1, rnd.randrange(1, R))
+        hs.hs_glv_phi(p, o64)
+        assert o64.raw == oracle.g1_mul(p, lam)
