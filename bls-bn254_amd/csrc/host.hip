@@ -40,6 +40,7 @@ struct blsbn254_ctx {
   DevBuf fe[6];          // final-exponentiation phase buffers (x, a, b, c, b2, d), 108 x n limbs each
   DevBuf rlc_a2, rlc_a, rlc_b, rlc_elig, rlc_f2, rlc_bytes, rlc_neg, rlc_ok, rlc_idx, rlc_cpk, rlc_csig, rlc_ch, rlc_csub, rlc_cbm;   // RLC batch verification
   DevBuf status_all;     // per-element decode status of a chunked call, all chunks
+  DevBuf q_ws;           // decoded public keys of the two-pairs-per-lane Miller kernel, 72 x lanes limbs
   DevBuf th_x, th_num, th_den, th_glv, th_part, th_part2;   // threshold combine: ids, partial products, GLV halves, window sums
   DevBuf fe_slots;       // the ten named powers of the t -> t^x addition chain, 10 x 108 x n limbs
   uint8_t dst_host[256];  // the (pre-hashed if oversize) DST currently resident in `dst`, and its length; -1 = none
@@ -121,7 +122,7 @@ void blsbn254_ctx_destroy(blsbn254_ctx* c) {
   for (DevBuf* b : bufs) b->release();
   for (DevBuf& b : c->fe) b.release();
   c->fe_slots.release();
-  { DevBuf* tb[] = {&c->th_x, &c->th_num, &c->th_den, &c->th_glv, &c->th_part, &c->th_part2}; for (DevBuf* b : tb) b->release(); }
+  { DevBuf* tb[] = {&c->th_x, &c->th_num, &c->th_den, &c->th_glv, &c->th_part, &c->th_part2, &c->q_ws}; for (DevBuf* b : tb) b->release(); }
   { DevBuf* rb[] = {&c->rlc_a2, &c->rlc_a, &c->rlc_b, &c->rlc_elig, &c->rlc_f2, &c->rlc_bytes, &c->rlc_neg, &c->rlc_ok, &c->rlc_idx, &c->rlc_cpk, &c->rlc_csig, &c->rlc_ch, &c->rlc_csub, &c->rlc_cbm};
     for (DevBuf* b : rb) b->release(); }
   (void)hipStreamDestroy(c->stream);
@@ -424,7 +425,7 @@ static int h2c_common(blsbn254_ctx* c, const uint8_t* msgs, const uint64_t* off,
   size_t sz = g2 ? 128 : 64;
   HIPCHK(c, c->out.reserve(sz * n));
   if (g2) { LAUNCH(c, "hash_to_g2", k_hash_to_g2, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (uint8_t*)c->out.p, ro); }
-  else { LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (int32_t*)nullptr, (uint8_t*)c->out.p, ro ? 1 : 2); }
+  else { LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (int32_t*)nullptr, n, (uint8_t*)c->out.p, ro ? 1 : 2); }
   HIPCHK(c, hipMemcpyAsync(out, c->out.p, sz * n, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
@@ -458,7 +459,7 @@ static int verify_chunk_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t
                             const uint8_t* d_sigs, size_t n, uint32_t dl, uint8_t* d_bitmap) {
   HIPCHK(c, c->h_ws.reserve(n * 18 * 4)); HIPCHK(c, c->f_ws.reserve(n * 108 * 4));
   HIPCHK(c, c->flags.reserve(n)); HIPCHK(c, c->sub_ok.reserve(n));
-  LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, d_msgs, d_off, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, (uint8_t*)nullptr, 0);
+  LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, d_msgs, d_off, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, n, (uint8_t*)nullptr, 0);
   LAUNCH(c, "g2_check", k_g2_check, n, d_pks, n, (uint8_t*)c->sub_ok.p, (uint8_t*)nullptr);
   LAUNCH(c, "miller_verify", k_miller_verify, n, d_pks, d_sigs, (const int32_t*)c->h_ws.p, n, (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
   return run_final_exp(c, (int32_t*)c->f_ws.p, n, n, 0, (const uint8_t*)c->flags.p, (const uint8_t*)c->sub_ok.p, d_bitmap, nullptr, nullptr);
@@ -514,7 +515,7 @@ int blsbn254_verify_batch_rlc(blsbn254_ctx* c, const uint8_t* pks, const uint8_t
     HIPCHK(c, hipStreamSynchronize(c->stream)); }
   const uint8_t* d_pks = (const uint8_t*)c->in_a.p; const uint8_t* d_sigs = (const uint8_t*)c->in_b.p;
   int32_t* f = (int32_t*)c->f_ws.p;
-  LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, (uint8_t*)nullptr, 0);
+  LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, n, (uint8_t*)nullptr, 0);
   LAUNCH(c, "g2_check", k_g2_check, n, d_pks, n, (uint8_t*)c->sub_ok.p, (uint8_t*)nullptr);
   LAUNCH(c, "rlc_prep", k_rlc_prep, n_pad, d_pks, d_sigs, (const int32_t*)c->h_ws.p, (const uint8_t*)c->sub_ok.p, (const uint8_t*)c->misc.p,
          n, n_pad, (int32_t*)c->rlc_a.p, (int32_t*)c->rlc_b.p, (uint8_t*)c->rlc_elig.p);
@@ -599,70 +600,108 @@ static int fp12_tree(blsbn254_ctx* c, int32_t* a, size_t cnt, size_t sa, int32_t
   *res = a; *rs = sa;
   return 0;
 }
+// prod_i ML(H(msg_i), pk_i) over the caller's n pairs, optionally times ML(extra_sig, -G2gen): the aggregate signature
+// then simply joins the batch as pair n (one more lane half among the million) instead of a latency-bound one-lane launch.
+// Two pairs per lane sharing one f^2 (k_miller_hpk2), then the pairwise product tree.
+static int aggregate_partial_impl(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
+                                  const uint8_t* dst, size_t dst_len, const uint8_t* extra_sig, uint8_t ml_out[384], int* all_pks_ok, int* sig_ok) {
+  *all_pks_ok = 1;
+  if (sig_ok) *sig_ok = 1;
+  const size_t np = n + (extra_sig ? 1 : 0);                 // pairs in the loop
+  if (np == 0) { std::memset(ml_out, 0, 384); ml_out[31] = 1; return 0; }
+  CHECK_LANES(c, np);
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t dl = 0; int rc;
+  if (n) {
+    rc = stage_dst(c, dst, dst_len, &dl);
+    if (rc) return rc;
+    rc = stage_msgs(c, msgs, off, n);
+    if (rc) return rc;
+  }
+  const size_t n_lanes = (np + 1) / 2;
+  HIPCHK(c, c->in_a.reserve(128 * np)); HIPCHK(c, c->in_b.reserve(64)); HIPCHK(c, c->h_ws.reserve(np * 18 * 4)); HIPCHK(c, c->f_ws.reserve(n_lanes * 108 * 4));
+  HIPCHK(c, c->q_ws.reserve(n_lanes * 72 * 4));
+  HIPCHK(c, c->flags.reserve(np)); HIPCHK(c, c->sub_ok.reserve(np)); HIPCHK(c, c->misc.reserve(64)); HIPCHK(c, c->out.reserve(384));
+  if (n) HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * n, hipMemcpyHostToDevice, c->stream));
+  int32_t* f = (int32_t*)c->f_ws.p;
+  int* d_ok = (int*)c->misc.p;                               // [0] all keys valid, [1] (byte) signature valid
+  static const int ones[2] = {1, 1};
+  HIPCHK(c, hipMemcpyAsync(d_ok, ones, 8, hipMemcpyHostToDevice, c->stream));
+  // hash and key checks over the caller's n pairs; their H points land in slots 0..n-1 of a stride-np workspace
+  if (n) {
+    LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, np, (uint8_t*)nullptr, 0);
+    LAUNCH(c, "g2_check", k_g2_check, n, (const uint8_t*)c->in_a.p, n, (uint8_t*)c->sub_ok.p, (uint8_t*)nullptr);
+  }
+  if (extra_sig) {
+    HIPCHK(c, hipMemcpyAsync(c->in_b.p, extra_sig, 64, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync((uint8_t*)c->in_a.p + 128 * n, NEG_G2_BYTES, 128, hipMemcpyHostToDevice, c->stream));
+    LAUNCH(c, "g1_to_ws", k_g1_to_ws, 1, (const uint8_t*)c->in_b.p, (int32_t*)c->h_ws.p, n, np, (uint8_t*)(d_ok + 1));
+  }
+  LAUNCH(c, "miller_hpk2", k_miller_hpk2, n_lanes, (const int32_t*)c->h_ws.p, (const uint8_t*)c->in_a.p, np, (int32_t*)c->q_ws.p, f, n_lanes, (uint8_t*)c->flags.p);
+  if (n) { LAUNCH(c, "and_reduce", k_and_reduce, n, (const uint8_t*)c->flags.p, (const uint8_t*)c->sub_ok.p, n, d_ok); }
+  int32_t* res; size_t rs;
+  rc = fp12_tree(c, f, n_lanes, n_lanes, &res, &rs);
+  if (rc) return rc;
+  LAUNCH(c, "fp12_to_bytes", k_fp12_to_bytes, 1, (const int32_t*)res, (size_t)1, rs, (uint8_t*)c->out.p);
+  int h_ok[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(ml_out, c->out.p, 384, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(h_ok, d_ok, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *all_pks_ok = h_ok[0];
+  if (sig_ok) *sig_ok = (h_ok[1] & 0xff) == 1;
+  return 0;
+}
 int blsbn254_aggregate_partial(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
                                const uint8_t* dst, size_t dst_len, uint8_t ml_out[384], int* all_pks_ok) {
   if (!c || !ml_out || !all_pks_ok || !off || (n && !pks) || (dst_len && !dst)) return BLSBN254_E_ARG;
-  *all_pks_ok = 1;
-  if (n == 0) { std::memset(ml_out, 0, 384); ml_out[31] = 1; return 0; }
-  CHECK_LANES(c, n);
-  HIPCHK(c, hipSetDevice(c->device));
-  uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
-  if (rc) return rc;
-  rc = stage_msgs(c, msgs, off, n);
-  if (rc) return rc;
-  HIPCHK(c, c->in_a.reserve(128 * n)); HIPCHK(c, c->h_ws.reserve(n * 18 * 4)); HIPCHK(c, c->f_ws.reserve(n * 108 * 4));
-  HIPCHK(c, c->flags.reserve(n)); HIPCHK(c, c->sub_ok.reserve(n)); HIPCHK(c, c->misc.reserve(64)); HIPCHK(c, c->out.reserve(384));
-  HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * n, hipMemcpyHostToDevice, c->stream));
-  int32_t* f = (int32_t*)c->f_ws.p;
-  LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, (uint8_t*)nullptr, 0);
-  LAUNCH(c, "g2_check", k_g2_check, n, (const uint8_t*)c->in_a.p, n, (uint8_t*)c->sub_ok.p, (uint8_t*)nullptr);
-  LAUNCH(c, "miller_hpk", k_miller_hpk, n, (const int32_t*)c->h_ws.p, (const uint8_t*)c->in_a.p, n, f, n, (uint8_t*)c->flags.p);
-  int* d_ok = (int*)c->misc.p;
-  int one = 1;
-  HIPCHK(c, hipMemcpyAsync(d_ok, &one, 4, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  LAUNCH(c, "and_reduce", k_and_reduce, n, (const uint8_t*)c->flags.p, (const uint8_t*)c->sub_ok.p, n, d_ok);
-  int32_t* res; size_t rs;
-  rc = fp12_tree(c, f, n, n, &res, &rs);
-  if (rc) return rc;
-  LAUNCH(c, "fp12_to_bytes", k_fp12_to_bytes, 1, (const int32_t*)res, (size_t)1, rs, (uint8_t*)c->out.p);
-  HIPCHK(c, hipMemcpyAsync(ml_out, c->out.p, 384, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(all_pks_ok, d_ok, 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return 0;
+  return aggregate_partial_impl(c, pks, msgs, off, n, dst, dst_len, nullptr, ml_out, all_pks_ok, nullptr);
+}
+// The first shard of a sharded aggregate verify may carry the aggregate signature's pair as well (then the finishing
+// call passes agg_sig = NULL): *sig_ok = the signature decodes, is not the identity and is on the curve.
+int blsbn254_aggregate_partial_with_sig(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
+                                        const uint8_t* dst, size_t dst_len, const uint8_t agg_sig[64], uint8_t ml_out[384], int* all_pks_ok, int* sig_ok) {
+  if (!c || !ml_out || !all_pks_ok || !sig_ok || !agg_sig || !off || (n && !pks) || (dst_len && !dst)) return BLSBN254_E_ARG;
+  return aggregate_partial_impl(c, pks, msgs, off, n, dst, dst_len, agg_sig, ml_out, all_pks_ok, sig_ok);
 }
 int blsbn254_aggregate_finish(blsbn254_ctx* c, const uint8_t* partials, size_t k, const uint8_t agg_sig[64], int* valid) {
-  if (!c || !valid || !agg_sig || (k && !partials)) return BLSBN254_E_ARG;
+  if (!c || !valid || (k && !partials) || (!k && !agg_sig)) return BLSBN254_E_ARG;
   *valid = 0;
   HIPCHK(c, hipSetDevice(c->device));
-  size_t m = k + 1;                                   // slot k holds ML(agg_sig, -G2gen)
+  const bool with_sig = agg_sig != nullptr;                // NULL: a partial already carries ML(agg_sig, -G2gen)
+  size_t m = k + (with_sig ? 1 : 0);                       // slot k holds ML(agg_sig, -G2gen)
   HIPCHK(c, c->in_a.reserve(384 * (k ? k : 1))); HIPCHK(c, c->in_b.reserve(64 + 128)); HIPCHK(c, c->f_ws.reserve(m * 108 * 4));
   HIPCHK(c, c->status.reserve(k + 8)); HIPCHK(c, c->misc.reserve(64)); HIPCHK(c, c->bitmap.reserve(16));
   int32_t* f = (int32_t*)c->f_ws.p;
-  uint8_t last[64 + 128];
-  std::memcpy(last, agg_sig, 64); std::memcpy(last + 64, NEG_G2_BYTES, 128);
-  HIPCHK(c, hipMemcpyAsync(c->in_b.p, last, sizeof last, hipMemcpyHostToDevice, c->stream));
-  if (k) HIPCHK(c, hipMemcpyAsync(c->in_a.p, partials, 384 * k, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));         // `last` is on the stack
+  if (with_sig) {
+    uint8_t last[64 + 128];
+    std::memcpy(last, agg_sig, 64); std::memcpy(last + 64, NEG_G2_BYTES, 128);
+    HIPCHK(c, hipMemcpyAsync(c->in_b.p, last, sizeof last, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));       // `last` is on the stack
+  }
   if (k) {
+    HIPCHK(c, hipMemcpyAsync(c->in_a.p, partials, 384 * k, hipMemcpyHostToDevice, c->stream));
     // partials arrive as bytes: decode into slots 0..k-1 of the stride-m array
     LAUNCH(c, "fp12_from_bytes", k_fp12_from_bytes, k, (const uint8_t*)c->in_a.p, k, f, m, (uint8_t*)c->status.p);
     int bad; int rc = first_bad(c, (const uint8_t*)c->status.p, k, 1, 1, &bad);
     if (rc) return rc;
     if (bad >= 0) return BLSBN254_ERR_GT;
   }
-  LAUNCH(c, "miller_1", k_miller_1, 1, (const uint8_t*)c->in_b.p, (const uint8_t*)c->in_b.p + 64, (size_t)1, f + k, m, (uint8_t*)c->status.p);
-  LAUNCH(c, "g1_check", k_g1_check, 1, (const uint8_t*)c->in_b.p, (size_t)1, (uint8_t*)c->bitmap.p);
+  if (with_sig) {
+    LAUNCH(c, "miller_1", k_miller_1, 1, (const uint8_t*)c->in_b.p, (const uint8_t*)c->in_b.p + 64, (size_t)1, f + k, m, (uint8_t*)c->status.p);
+    LAUNCH(c, "g1_check", k_g1_check, 1, (const uint8_t*)c->in_b.p, (size_t)1, (uint8_t*)c->bitmap.p);
+  }
   int32_t* res; size_t rs;
   int rc = fp12_tree(c, f, m, m, &res, &rs);
   if (rc) return rc;
   int* d_one = (int*)c->misc.p;
   rc = run_final_exp(c, res, 1, rs, 3, nullptr, nullptr, nullptr, nullptr, d_one);
   if (rc) return rc;
-  int h_one = 0; uint8_t sig_st, sig_on_curve;
+  int h_one = 0; uint8_t sig_st = 3, sig_on_curve = 1;
   HIPCHK(c, hipMemcpyAsync(&h_one, d_one, 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(&sig_st, c->status.p, 1, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(&sig_on_curve, c->bitmap.p, 1, hipMemcpyDeviceToHost, c->stream));
+  if (with_sig) {
+    HIPCHK(c, hipMemcpyAsync(&sig_st, c->status.p, 1, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&sig_on_curve, c->bitmap.p, 1, hipMemcpyDeviceToHost, c->stream));
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   bool sig_ok = (sig_st & 7) == 3 && (sig_on_curve & 1);      // decodes, not the identity, on the curve
   *valid = (sig_ok && h_one == 1) ? 1 : 0;
@@ -673,12 +712,13 @@ int blsbn254_aggregate_verify(blsbn254_ctx* c, const uint8_t* pks, const uint8_t
   if (!c || !valid || !agg_sig || !off || (n && !pks) || (dst_len && !dst)) return BLSBN254_E_ARG;
   *valid = 0;
   if (n == 0) return 0;
-  uint8_t ml[384]; int ok = 0, v = 0;
-  int rc = blsbn254_aggregate_partial(c, pks, msgs, off, n, dst, dst_len, ml, &ok);
+  if (n + 1 > MAX_LANES) { c->last_error = "more than 2^23 - 1 pairs in one aggregate_verify call"; return BLSBN254_E_ARG; }
+  uint8_t ml[384]; int ok = 0, sig_ok = 0, v = 0;
+  int rc = aggregate_partial_impl(c, pks, msgs, off, n, dst, dst_len, agg_sig, ml, &ok, &sig_ok);
   if (rc) return rc;
-  rc = blsbn254_aggregate_finish(c, ml, 1, agg_sig, &v);
+  rc = blsbn254_aggregate_finish(c, ml, 1, nullptr, &v);
   if (rc) return rc;
-  *valid = (ok == 1 && v == 1) ? 1 : 0;
+  *valid = (ok == 1 && sig_ok == 1 && v == 1) ? 1 : 0;
   return 0;
 }
 // n G1 points (limb-major projective, stride n) in c->h_ws -> their sum as 64 bytes

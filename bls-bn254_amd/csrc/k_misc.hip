@@ -51,6 +51,17 @@ BN_KERNEL k_g1_load(const uint8_t* g1, size_t n, int32_t* ws, uint8_t* status) {
   store_g1p(ws + i, n, proj_from_affine(a));
   status[i] = ok ? 1 : 0;
 }
+// one G1 point (64 bytes) -> affine Montgomery limbs in slot `slot` of a limb-major H workspace; *ok = decodes, not the
+// identity, on the curve (the aggregate signature joins the batch of (H(msg), pk) pairs as the pair (sig, -G2gen))
+BN_KERNEL k_g1_to_ws(const uint8_t* g1, int32_t* h_ws, size_t slot, size_t stride, uint8_t* ok) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  bool okd;
+  G1A p = g1_decode(g1, okd);
+  const bool good = okd & !p.inf & g1_on_curve(p);
+  G1A gp; gp.x = fp_one(); gp.y = fp_norm(fp_add(fp_one(), fp_one()));
+  store_fp(h_ws + slot, stride, fp_select(good, p.x, gp.x)); store_fp(h_ws + 9 * stride + slot, stride, fp_select(good, p.y, gp.y));
+  *ok = good ? 1 : 0;
+}
 BN_KERNEL k_g1_add_pairs(const int32_t* in, size_t n_in, size_t in_stride, int32_t* out, size_t out_stride) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t n_out = (n_in + 1) >> 1;

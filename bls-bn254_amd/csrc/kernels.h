@@ -22,13 +22,15 @@ __device__ inline void write_ballot(uint8_t* bitmap, size_t n, size_t i, bool bi
 #endif
 
 BN_KERNEL k_hash_to_g1(const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
-                       int32_t* h_ws, uint8_t* out_bytes, int mode);
+                       int32_t* h_ws, size_t h_stride, uint8_t* out_bytes, int mode);
 BN_KERNEL k_hash_to_g2(const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
                        uint8_t* out_bytes, int ro);
 BN_KERNEL k_g1_check(const uint8_t* g1, size_t n, uint8_t* bitmap);
 BN_KERNEL k_g2_check(const uint8_t* g2, size_t n, uint8_t* ok_bytes, uint8_t* bitmap);
 BN_KERNEL k_miller_1(const uint8_t* g1, const uint8_t* g2, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status);
 BN_KERNEL k_miller_hpk(const int32_t* h_ws, const uint8_t* pks, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* flags);
+BN_KERNEL k_miller_hpk2(const int32_t* h_ws, const uint8_t* pks, size_t n, int32_t* q_ws, int32_t* f_ws, size_t f_stride, uint8_t* flags);
+BN_KERNEL k_g1_to_ws(const uint8_t* g1, int32_t* h_ws, size_t slot, size_t stride, uint8_t* ok);
 BN_KERNEL k_miller_verify(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n, int32_t* f_ws, uint8_t* flags);
 BN_KERNEL k_fe_easy(const int32_t* in, int32_t* out, size_t n, size_t stride);
 BN_KERNEL k_fe_expx(const int32_t* in, int32_t* out, int32_t* slots, size_t n, size_t stride);

@@ -136,19 +136,23 @@ int blsbn254_aggregate_verify_multi(blsbn254_multi* m, const uint8_t* pks, const
   std::vector<int> rcs(G, 0), oks(G, 1);
   std::vector<uint8_t> partials(384 * G);
   std::vector<std::thread> th;
+  int sig_ok = 0;
   for (size_t g = 0; g < G; ++g) {
     const size_t lo = n * g / G, hi = n * (g + 1) / G;
-    th.emplace_back([=, &rcs, &oks, &partials]() {
-      rcs[g] = blsbn254_aggregate_partial(m->ctx[g], pks + 128 * lo, msgs, off + lo, hi - lo, dst, dst_len, partials.data() + 384 * g, &oks[g]);
+    th.emplace_back([=, &rcs, &oks, &partials, &sig_ok]() {
+      if (g == 0)      // the first device also carries the pair (agg_sig, -G2gen)
+        rcs[g] = blsbn254_aggregate_partial_with_sig(m->ctx[g], pks + 128 * lo, msgs, off + lo, hi - lo, dst, dst_len, agg_sig, partials.data(), &oks[g], &sig_ok);
+      else
+        rcs[g] = blsbn254_aggregate_partial(m->ctx[g], pks + 128 * lo, msgs, off + lo, hi - lo, dst, dst_len, partials.data() + 384 * g, &oks[g]);
     });
   }
   for (std::thread& t : th) t.join();
   int rc = first_rc(m, rcs);
   if (rc) return rc;
   int v = 0;
-  rc = blsbn254_aggregate_finish(m->ctx[0], partials.data(), G, agg_sig, &v);
+  rc = blsbn254_aggregate_finish(m->ctx[0], partials.data(), G, nullptr, &v);
   if (rc) { m->last_error = blsbn254_last_error(m->ctx[0]); return rc; }
-  bool all_ok = true;
+  bool all_ok = sig_ok == 1;
   for (int o : oks) all_ok &= o == 1;
   *valid = (all_ok && v == 1) ? 1 : 0;
   return 0;

@@ -79,6 +79,7 @@ BN_FUNC Fp12 ell2(const Fp12& f, const Line& la, const Fp& pax, const Fp& pay, c
   BN_CTX;
   return fp12_mul_by_two_lines(f, fp2_mul_fp(la.c0, pay), fp2_mul_fp(la.c1, pax), la.c2, fp2_mul_fp(lb.c0, pby), fp2_mul_fp(lb.c1, pbx), lb.c2);
 }
+BN_INL Line fp2_norm_line(const Line& l) { return {fp2_norm(l.c0), fp2_norm(l.c1), fp2_norm(l.c2)}; }
 BN_INL Line line_from_table(const int32_t* t) {                  // 54 strict limbs from the generated table
   return {fp2_from_limbs(t), fp2_from_limbs(t + 18), fp2_from_limbs(t + 36)};
 }
@@ -194,6 +195,69 @@ BN_FUNC Fp12 miller_loop_verify_ws(const Ws& inv, const int32_t (*table)[54]) {
   l = addition_step(T, q2x, q2y);
   BN_OPAQUE(p);
   f = ell2(f, line_from_table(table[ti++]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)), l, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
+  return f;
+}
+
+// Two VARIABLE pairs per lane sharing one f^2 per digit (multi_miller_loop, pairings.rs:808-857: "one shared f.square()
+// per bit for all terms"): f = ML(Ha, Qa) * ML(Hb, Qb), bit-identical to the product of the two one-pair loops because the
+// arithmetic is exact.  Used by aggregate verify (k_miller_hpk2.hip).  Register budget = that of the verify loop: only ONE
+// running point T is in registers at a time; the other waits in `park` (LDS, 54 limbs), and the first line of a step waits
+// in `lpark` (LDS, 54 limbs) while the second is computed.  `hh` (LDS) holds Ha.x, Ha.y, Hb.x, Hb.y (9 limbs each); `qw`
+// (HBM workspace, limb-major) holds Qa.x, Qa.y, Qb.x, Qb.y (18 limbs each), read in the addition steps only.
+// live_a / live_b: a pair that is padding (odd count) or failed validation contributes the line 1, i.e. nothing.
+BN_INL void g2j_store(const Ws& w, const G2J& t) { fp2_store_mem(w, t.x); fp2_store_mem(ws_at(w, 18), t.y); fp2_store_mem(ws_at(w, 36), t.z); }
+BN_INL G2J g2j_load(const Ws& w) { return {fp2_load_mem(w), fp2_load_mem(ws_at(w, 18)), fp2_load_mem(ws_at(w, 36))}; }
+BN_INL void line_store(const Ws& w, const Line& l) { fp2_store_mem(w, l.c0); fp2_store_mem(ws_at(w, 18), l.c1); fp2_store_mem(ws_at(w, 36), l.c2); }
+BN_INL Line line_load(const Ws& w) { return {fp2_load_mem(w), fp2_load_mem(ws_at(w, 18)), fp2_load_mem(ws_at(w, 36))}; }
+BN_INL Line line_mask(bool live, const Line& l) {               // live ? l : the constant line 1
+  return {fp2_select(live, l.c0, fp2_one()), fp2_select(live, l.c1, fp2_zero()), fp2_select(live, l.c2, fp2_zero())};
+}
+// one line step for both pairs: kind 0 doubling, 1 addition with (qx, +-qy) read from qw, 2 / 3 the two Frobenius additions
+template <int KIND>
+BN_FUNC Fp12 miller2_step(const Fp12& f_in, G2J& T, const Ws& park, const Ws& lpark, const Ws& hh_in, const Ws& qw_in, bool negq, bool live_a, bool live_b) {
+  Ws hh = hh_in, qw = qw_in, pk = park, lp = lpark;
+  BN_OPAQUE(hh); BN_OPAQUE(qw); BN_OPAQUE(pk); BN_OPAQUE(lp);
+  const Fp2 g2 = fp2_const(bnc::GAMMA1[1]), g3 = fp2_const(bnc::GAMMA1[2]);
+  auto q_of = [&](int pair, Fp2& qx, Fp2& qy) {
+    qx = fp2_load_mem(ws_at(qw, 36 * pair)); qy = fp2_load_mem(ws_at(qw, 36 * pair + 18));
+    if (KIND == 1) qy = fp2_select(negq, fp2_norm(fp2_neg(qy)), qy);
+    if (KIND >= 2) { qx = fp2_mul(fp2_norm(fp2_conj(qx)), g2); qy = fp2_mul(fp2_norm(fp2_conj(qy)), g3); }                        // pi(Q)
+    if (KIND == 3) { qx = fp2_mul(fp2_norm(fp2_conj(qx)), g2); qy = fp2_norm(fp2_neg(fp2_mul(fp2_norm(fp2_conj(qy)), g3))); }     // -pi^2(Q)
+  };
+  Line la;
+  if (KIND == 0) la = doubling_step(T);
+  else { Fp2 qx, qy; q_of(0, qx, qy); la = addition_step(T, qx, qy); }
+  line_store(lp, fp2_norm_line(line_mask(live_a, la)));
+  // swap the running points: Ta -> park, Tb <- park
+  G2J Tb = g2j_load(pk);
+  BN_MEM_FENCE;
+  g2j_store(pk, T);
+  BN_MEM_FENCE;
+  Line lb;
+  if (KIND == 0) lb = doubling_step(Tb);
+  else { Fp2 qx, qy; q_of(1, qx, qy); lb = addition_step(Tb, qx, qy); }
+  lb = line_mask(live_b, lb);
+  T = g2j_load(pk);
+  BN_MEM_FENCE;
+  g2j_store(pk, Tb);
+  BN_MEM_FENCE;
+  la = line_load(lp);
+  Fp hax = fp_load_mem(hh), hay = fp_load_mem(ws_at(hh, 9)), hbx = fp_load_mem(ws_at(hh, 18)), hby = fp_load_mem(ws_at(hh, 27));
+  return ell2(f_in, la, hax, hay, lb, hbx, hby);
+}
+BN_FUNC Fp12 miller_loop_2var_ws(const Ws& hh, const Ws& qw, const Ws& park, const Ws& lpark, bool live_a, bool live_b) {
+  Fp12 f = fp12_one();
+  G2J T = {fp2_load_mem(qw), fp2_load_mem(ws_at(qw, 18)), fp2_one()};                       // Ta = Qa
+  g2j_store(park, G2J{fp2_load_mem(ws_at(qw, 36)), fp2_load_mem(ws_at(qw, 54)), fp2_one()});   // Tb = Qb
+  BN_MEM_FENCE;
+  for (int j = bnc::ATE_NAF_LEN - 2; j >= 0; --j) {
+    f = fp12_sqr(f);
+    f = miller2_step<0>(f, T, park, lpark, hh, qw, false, live_a, live_b);
+    int d = ate_naf_digit(j);
+    if (d != 0) f = miller2_step<1>(f, T, park, lpark, hh, qw, d < 0, live_a, live_b);
+  }
+  f = miller2_step<2>(f, T, park, lpark, hh, qw, false, live_a, live_b);
+  f = miller2_step<3>(f, T, park, lpark, hh, qw, false, live_a, live_b);
   return f;
 }
 

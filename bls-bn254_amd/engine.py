@@ -227,8 +227,23 @@ class Engine:
                                                        ctypes.c_size_t(len(dst)), po, ctypes.byref(ok)))
         return o.tobytes(), bool(ok.value)
 
+    def aggregate_partial_with_sig(self, pks, msgs, agg_sig, dst=DEFAULT_DST):
+        """(partial product times ML(agg_sig, -G2gen), all public keys valid?, signature valid?): the shard that carries
+        the aggregate signature's pair; finish with aggregate_finish(partials, k, None)."""
+        n = len(msgs)
+        data, off = pack_messages(msgs)
+        a, pa = _inbuf(pks, 128 * n); m, pm = _inbuf(data); d, pd = _inbuf(dst); s, ps = _inbuf(agg_sig, 64); o, po = _outbuf(384)
+        ok = ctypes.c_int(0); sok = ctypes.c_int(0)
+        self._chk(self._lib.blsbn254_aggregate_partial_with_sig(self._ctx, pa, pm, off.ctypes.data_as(_u64p), ctypes.c_size_t(n), pd,
+                                                                ctypes.c_size_t(len(dst)), ps, po, ctypes.byref(ok), ctypes.byref(sok)))
+        return o.tobytes(), bool(ok.value), bool(sok.value)
+
     def aggregate_finish(self, partials, k, agg_sig):
-        a, pa = _inbuf(partials, 384 * k); s, ps = _inbuf(agg_sig, 64)
+        a, pa = _inbuf(partials, 384 * k)
+        if agg_sig is None:
+            s, ps = None, ctypes.cast(None, _u8p)
+        else:
+            s, ps = _inbuf(agg_sig, 64)
         valid = ctypes.c_int(0)
         self._chk(self._lib.blsbn254_aggregate_finish(self._ctx, pa, ctypes.c_size_t(k), ps, ctypes.byref(valid)))
         return bool(valid.value)

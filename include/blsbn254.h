@@ -108,6 +108,12 @@ int blsbn254_aggregate_verify(blsbn254_ctx* ctx, const uint8_t* pks, const uint8
 int blsbn254_aggregate_partial(blsbn254_ctx* ctx, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
                                const uint8_t* dst, size_t dst_len, uint8_t ml_out[384], int* all_pks_ok);
 int blsbn254_aggregate_finish(blsbn254_ctx* ctx, const uint8_t* partials /* k*384 */, size_t k, const uint8_t agg_sig[64], int* valid);
+/* One shard may carry the aggregate signature's pair as well: its partial is then prod_i ML(H(msg_i), pk_i) * ML(agg_sig, -G2gen)
+ * (the signature joins the batch as one more pair instead of a one-lane launch of its own), *sig_ok = the signature decodes,
+ * is not the identity and is on the curve, and blsbn254_aggregate_finish is called with agg_sig = NULL. */
+int blsbn254_aggregate_partial_with_sig(blsbn254_ctx* ctx, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
+                                        const uint8_t* dst, size_t dst_len, const uint8_t agg_sig[64], uint8_t ml_out[384],
+                                        int* all_pks_ok, int* sig_ok);
 /* Same result as blsbn254_verify_batch (same bitmap), computed with random linear combinations (SURVEY.md 8f
  * rank 4): groups of 16 tuples share ONE final exponentiation,
  *   prod_i [e(sig_i,-G2gen) e(H_i,pk_i)]^(r_i) = e(sum r_i sig_i, -G2gen) * prod_i e(r_i H_i, pk_i),

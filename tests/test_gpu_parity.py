@@ -368,6 +368,20 @@ def test_aggregate_partial_finish(eng, oracle, M):
     assert eng.aggregate_finish(p0 + p1 + pe, 3, agg) is True
     assert eng.aggregate_finish(p0, 1, agg) is False
     assert eng.aggregate_partial(synth.NON_SUBGROUP_PK, [b"m"], dst)[1] is False
+    # every split of the 21 pairs (odd and even shard sizes: the two-pairs-per-lane kernel pads the odd ones with the
+    # constant line 1) gives the oracle's Miller product bit for bit
+    hall = oracle.hash_to_g1_batch(msgs, dst)
+    for lo, hi in ((0, 1), (0, 2), (3, 6), (0, 21), (5, 21), (20, 21)):
+        assert eng.aggregate_partial(pks[128 * lo:128 * hi], msgs[lo:hi], dst)[0] == oracle.multi_miller_loop(hall[64 * lo:64 * hi], pks[128 * lo:128 * hi], hi - lo)
+    # the shard that carries the signature's pair: partial == oracle product over the n + 1 pairs (sig, -G2gen) included
+    from oracle.pyref import bn254 as B
+    neg_g2 = B.g2_to_bytes(B.g2_neg(B.G2_GEN))
+    ps, oks, sok = eng.aggregate_partial_with_sig(pks[:128 * 8], msgs[:8], agg, dst)
+    assert oks and sok and ps == oracle.multi_miller_loop(h + agg, pks[:128 * 8] + neg_g2, 9)
+    assert eng.aggregate_finish(ps + p1, 2, None) is True
+    assert eng.aggregate_finish(ps, 1, None) is False
+    assert eng.aggregate_partial_with_sig(pks[:128 * 8], msgs[:8], IDENT1, dst)[2] is False          # identity signature
+    assert eng.aggregate_partial_with_sig(pks[:128 * 8], msgs[:8], agg[:63] + bytes([agg[63] ^ 1]), dst)[2] is False   # off curve
 
 
 def test_randomized_differential(eng, oracle, pyref, M):
