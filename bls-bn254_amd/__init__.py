@@ -10,5 +10,5 @@ Layout:
   engine.py    ctypes binding of include/blsbn254.h with the reference's operator names
   sharded.py   one-process-per-GPU sharding over torch.distributed (RCCL)
 """
-from .engine import (Bn254Error, Engine, MultiEngine, InvalidG1Bytes, InvalidG2Bytes, InvalidGtBytes,  # noqa: F401
+from .engine import (Bn254Error, Engine, MultiEngine, PreparedKeys, InvalidG1Bytes, InvalidG2Bytes, InvalidGtBytes,  # noqa: F401
                      InvalidScalarBytes, DEFAULT_DST, POP_DST, library_path, load_library)

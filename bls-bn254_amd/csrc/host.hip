@@ -40,6 +40,13 @@ struct blsbn254_ctx {
   DevBuf fe[6];          // final-exponentiation phase buffers (x, a, b, c, b2, d), 108 x n limbs each
   DevBuf rlc_a2, rlc_a, rlc_b, rlc_elig, rlc_f2, rlc_bytes, rlc_neg, rlc_ok, rlc_idx, rlc_cpk, rlc_csig, rlc_ch, rlc_csub, rlc_cbm;   // RLC batch verification
   DevBuf status_all;     // per-element decode status of a chunked call, all chunks
+  // prepared-key verify path (k_keyprep.hip, k_miller_prep.hip)
+  DevBuf kd_slots, kd_rep, kd_kid, kd_keys, kd_hist, kd_cursor, kd_perm, kd_cnt, prep_table, prep_ok, prep_isone, prep_valid;
+  hipStream_t stream2 = nullptr;     // the per-key preparation runs beside hash-to-G1
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  uint32_t kd_seed = 0;              // per-context random seed of the key hash table
+  bool auto_prepare = true;          // verify_batch: de-duplicate the public keys and prepare each distinct key once (BLSBN254_AUTO_PREPARE=0 disables)
+  uint64_t stat_prepared_chunks = 0, stat_exact_chunks = 0;
   DevBuf q_ws;           // decoded public keys of the two-pairs-per-lane Miller kernel, 72 x lanes limbs
   DevBuf th_x, th_num, th_den, th_glv, th_part, th_part2;   // threshold combine: ids, partial products, GLV halves, window sums
   DevBuf fe_slots;       // the ten named powers of the t -> t^x addition chain, 10 x 108 x n limbs
@@ -67,6 +74,19 @@ struct ProfScope {
 };
 #define LAUNCH(ctx, name, kernel, n, ...) do { ProfScope ps_(ctx, name); \
     hipLaunchKernelGGL(kernel, dim3(nblocks(n)), dim3(256), 0, (ctx)->stream, __VA_ARGS__); } while (0); HIPCHK(ctx, hipGetLastError())
+
+// the same on the context's second stream (events recorded there)
+struct ProfScope2 {
+  blsbn254_ctx* c; const char* name; hipEvent_t e0 = nullptr, e1 = nullptr;
+  ProfScope2(blsbn254_ctx* c_, const char* n) : c(c_), name(n) {
+    if (c->profiling) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); (void)hipEventRecord(e0, c->stream2); }
+  }
+  ~ProfScope2() {
+    if (c->profiling) { (void)hipEventRecord(e1, c->stream2); ProfEntry& p = c->prof[name]; ++p.launches; p.pending.emplace_back(e0, e1); }
+  }
+};
+#define LAUNCH2(ctx, name, kernel, n, ...) do { ProfScope2 ps_(ctx, name); \
+    hipLaunchKernelGGL(kernel, dim3(nblocks(n)), dim3(256), 0, (ctx)->stream2, __VA_ARGS__); } while (0); HIPCHK(ctx, hipGetLastError())
 
 extern "C" {
 
@@ -110,6 +130,10 @@ int blsbn254_ctx_create(int device, blsbn254_ctx** out) {
     if (v >= 8 && v <= ((size_t)1 << 23)) c->chunk = v;
   }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return BLSBN254_E_HIP; }
+  if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return BLSBN254_E_HIP; }
+  if (getrandom(&c->kd_seed, sizeof c->kd_seed, 0) != (ssize_t)sizeof c->kd_seed) c->kd_seed = 0x5bd1e995u;
+  if (const char* e = std::getenv("BLSBN254_AUTO_PREPARE")) c->auto_prepare = std::atoi(e) != 0;
   *out = c;
   return 0;
 }
@@ -125,6 +149,12 @@ void blsbn254_ctx_destroy(blsbn254_ctx* c) {
   { DevBuf* tb[] = {&c->th_x, &c->th_num, &c->th_den, &c->th_glv, &c->th_part, &c->th_part2, &c->q_ws}; for (DevBuf* b : tb) b->release(); }
   { DevBuf* rb[] = {&c->rlc_a2, &c->rlc_a, &c->rlc_b, &c->rlc_elig, &c->rlc_f2, &c->rlc_bytes, &c->rlc_neg, &c->rlc_ok, &c->rlc_idx, &c->rlc_cpk, &c->rlc_csig, &c->rlc_ch, &c->rlc_csub, &c->rlc_cbm};
     for (DevBuf* b : rb) b->release(); }
+  { DevBuf* kb[] = {&c->kd_slots, &c->kd_rep, &c->kd_kid, &c->kd_keys, &c->kd_hist, &c->kd_cursor, &c->kd_perm, &c->kd_cnt, &c->prep_table, &c->prep_ok,
+                    &c->prep_isone, &c->prep_valid};
+    for (DevBuf* b : kb) b->release(); }
+  (void)hipStreamSynchronize(c->stream2);
+  (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join);
+  (void)hipStreamDestroy(c->stream2);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -455,8 +485,90 @@ int blsbn254_g2_check_batch(blsbn254_ctx* c, const uint8_t* g2, size_t n, uint8_
 // ---------------- verify
 // Workspace is ~7.4 KB per tuple (H, f, six final-exponentiation phase buffers, ten chain slots); batches
 // larger than ctx->chunk (4 Mi) tuples are processed chunk by chunk so that any n fits the 288 GB of HBM.
+// ---- prepared-key path.  Limits: key ids and table offsets are 32-bit (88 x 54 x 4 B per key): at most PREP_MAX_KEYS keys.
+static const size_t PREP_MAX_KEYS = (size_t)1 << 16;
+static const size_t PREP_KEY_LIMBS = (size_t)BN_NEG_G2_LINES * 54;
+
+// G2Prepared::from for u keys on the second stream (after ev_fork), ev_join recorded behind it.
+// keys == nullptr: key k = pks[128 k]; else key k = the public key of tuple keys[k].
+static int prepare_keys_async(blsbn254_ctx* c, const uint8_t* d_pks, const uint32_t* d_keys, size_t u, int32_t* table, uint8_t* key_ok) {
+  HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+  LAUNCH2(c, "g2_prepare", k_g2_prepare, u, d_pks, d_keys, (uint32_t)u, table, key_ok);
+  HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+  return 0;
+}
+// Verify n tuples whose keys are given by index into a prepared table (d_kid[i] < u), everything device-resident.
+// The caller has put the preparation of the table on stream2 (ev_join) or the table is final (join = false).
+static int verify_prepared_dev(blsbn254_ctx* c, const int32_t* table, const uint8_t* key_ok, size_t u, const uint32_t* d_kid, bool hist_done,
+                               const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs, size_t n, uint32_t dl, uint8_t* d_bitmap, bool join) {
+  HIPCHK(c, c->h_ws.reserve(n * 18 * 4)); HIPCHK(c, c->f_ws.reserve(n * 108 * 4)); HIPCHK(c, c->flags.reserve(n));
+  HIPCHK(c, c->kd_hist.reserve(4 * (u + 1))); HIPCHK(c, c->kd_cursor.reserve(4 * (u + 1))); HIPCHK(c, c->kd_perm.reserve(4 * n));
+  HIPCHK(c, c->prep_isone.reserve(n)); HIPCHK(c, c->prep_valid.reserve(n)); HIPCHK(c, c->misc.reserve(64));
+  uint32_t* hist = (uint32_t*)c->kd_hist.p; uint32_t* cursor = (uint32_t*)c->kd_cursor.p; uint32_t* perm = (uint32_t*)c->kd_perm.p;
+  LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, d_msgs, d_off, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, n, (uint8_t*)nullptr, 0);
+  if (!hist_done) {
+    int* d_bad = (int*)c->misc.p;
+    static const int init = 0x7fffffff;
+    HIPCHK(c, hipMemcpyAsync(d_bad, &init, 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(hist, 0, 4 * u, c->stream));
+    LAUNCH(c, "kd_hist", k_kd_hist, n, d_kid, (uint32_t)n, (uint32_t)u, hist, d_bad);
+    int bad;
+    HIPCHK(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (bad != 0x7fffffff) { c->last_error = "key index out of range at tuple " + std::to_string(bad); return BLSBN254_E_ARG; }
+  }
+  { ProfScope ps_(c, "kd_scan"); hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)hist, (uint32_t)u, cursor); }
+  HIPCHK(c, hipGetLastError());
+  LAUNCH(c, "kd_scatter", k_kd_scatter, n, d_kid, (uint32_t)n, (uint32_t)u, cursor, perm);
+  if (join) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  LAUNCH(c, "miller_prepared", k_miller_prepared, n, (const uint32_t*)perm, d_kid, d_sigs, (const int32_t*)c->h_ws.p, n, table, key_ok, n,
+         (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
+  int rc = run_final_exp(c, (int32_t*)c->f_ws.p, n, n, 4, nullptr, nullptr, nullptr, (uint8_t*)c->prep_isone.p, nullptr);
+  if (rc) return rc;
+  LAUNCH(c, "prep_unsort", k_prep_unsort, n, (const uint8_t*)c->prep_isone.p, (const uint8_t*)c->flags.p, (const uint32_t*)perm, (uint32_t)n, (uint8_t*)c->prep_valid.p);
+  LAUNCH(c, "pack_bitmap", k_pack_bitmap, n, (const uint8_t*)c->prep_valid.p, n, d_bitmap);
+  return 0;
+}
+// De-duplicate the public keys of a chunk.  *u_out = number of distinct keys; kd_kid / kd_keys / kd_hist are filled.
+static int dedup_keys(blsbn254_ctx* c, const uint8_t* d_pks, size_t n, size_t* u_out) {
+  size_t m = 1;
+  while (m < 2 * n) m <<= 1;
+  HIPCHK(c, c->kd_slots.reserve(4 * m)); HIPCHK(c, c->kd_rep.reserve(4 * n)); HIPCHK(c, c->kd_kid.reserve(4 * n)); HIPCHK(c, c->kd_keys.reserve(4 * n));
+  HIPCHK(c, c->kd_hist.reserve(4 * (n + 1))); HIPCHK(c, c->kd_cnt.reserve(64));
+  HIPCHK(c, hipMemsetAsync(c->kd_slots.p, 0xff, 4 * m, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->kd_cnt.p, 0, 4, c->stream));
+  LAUNCH(c, "kd_insert", k_kd_insert, n, d_pks, (uint32_t)n, (uint32_t*)c->kd_slots.p, (uint32_t)(m - 1), c->kd_seed, (uint32_t*)c->kd_rep.p);
+  LAUNCH(c, "kd_assign", k_kd_assign, n, (const uint32_t*)c->kd_rep.p, (uint32_t)n, (uint32_t*)c->kd_kid.p, (uint32_t*)c->kd_cnt.p, (uint32_t*)c->kd_keys.p);
+  uint32_t u = 0;
+  HIPCHK(c, hipMemcpyAsync(&u, c->kd_cnt.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *u_out = u;
+  return 0;
+}
+// Workspace is ~7.4 KB per tuple (H, f, six final-exponentiation phase buffers, ten chain slots); batches
+// larger than ctx->chunk (4 Mi) tuples are processed chunk by chunk so that any n fits the 288 GB of HBM.
 static int verify_chunk_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
                             const uint8_t* d_sigs, size_t n, uint32_t dl, uint8_t* d_bitmap) {
+  // Few distinct keys (a validator set signing many messages): every distinct key is validated and turned into its line
+  // table ONCE (G2Prepared), beside hash-to-G1, and the tuples run the table-only Miller loop in key-sorted order.
+  // Same bitmap as the exact per-tuple path below, which batches of mostly distinct keys keep taking.
+  if (c->auto_prepare && n >= 1024) {
+    size_t u = 0;
+    int rc = dedup_keys(c, d_pks, n, &u);
+    if (rc) return rc;
+    if (u * 2 <= n && u <= PREP_MAX_KEYS) {
+      HIPCHK(c, c->prep_table.reserve(u * PREP_KEY_LIMBS * 4)); HIPCHK(c, c->prep_ok.reserve(u));
+      rc = prepare_keys_async(c, d_pks, (const uint32_t*)c->kd_keys.p, u, (int32_t*)c->prep_table.p, (uint8_t*)c->prep_ok.p);
+      if (rc) return rc;
+      HIPCHK(c, hipMemsetAsync(c->kd_hist.p, 0, 4 * u, c->stream));
+      LAUNCH(c, "kd_propagate", k_kd_propagate, n, (const uint32_t*)c->kd_rep.p, (uint32_t)n, (uint32_t*)c->kd_kid.p, (uint32_t*)c->kd_hist.p);
+      ++c->stat_prepared_chunks;
+      return verify_prepared_dev(c, (const int32_t*)c->prep_table.p, (const uint8_t*)c->prep_ok.p, u, (const uint32_t*)c->kd_kid.p, true,
+                                 d_msgs, d_off, d_sigs, n, dl, d_bitmap, true);
+    }
+  }
+  ++c->stat_exact_chunks;
   HIPCHK(c, c->h_ws.reserve(n * 18 * 4)); HIPCHK(c, c->f_ws.reserve(n * 108 * 4));
   HIPCHK(c, c->flags.reserve(n)); HIPCHK(c, c->sub_ok.reserve(n));
   LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, d_msgs, d_off, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, n, (uint8_t*)nullptr, 0);
@@ -478,6 +590,75 @@ int blsbn254_verify_batch_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8
   }
   return 0;
 }
+// ---------------- G2Prepared: explicit API
+struct blsbn254_g2prepared { blsbn254_ctx* ctx; size_t u; DevBuf table, ok; };
+int blsbn254_g2_prepare_batch(blsbn254_ctx* c, const uint8_t* pks, size_t u, blsbn254_g2prepared** out) {
+  if (!c || !out || (u && !pks)) return BLSBN254_E_ARG;
+  *out = nullptr;
+  if (u > PREP_MAX_KEYS) { c->last_error = "more than 65536 keys in one prepared table"; return BLSBN254_E_ARG; }
+  HIPCHK(c, hipSetDevice(c->device));
+  blsbn254_g2prepared* p = new blsbn254_g2prepared();
+  p->ctx = c; p->u = u;
+  if (u) {
+    hipError_t e1 = p->table.reserve(u * PREP_KEY_LIMBS * 4), e2 = p->ok.reserve(u), e3 = c->in_a.reserve(128 * u);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { p->table.release(); p->ok.release(); delete p; return BLSBN254_E_NOMEM; }
+    HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * u, hipMemcpyHostToDevice, c->stream));
+    LAUNCH(c, "g2_prepare", k_g2_prepare, u, (const uint8_t*)c->in_a.p, (const uint32_t*)nullptr, (uint32_t)u, (int32_t*)p->table.p, (uint8_t*)p->ok.p);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  *out = p;
+  return 0;
+}
+void blsbn254_g2prepared_destroy(blsbn254_g2prepared* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->ctx->device);
+  (void)hipStreamSynchronize(p->ctx->stream);
+  p->table.release(); p->ok.release();
+  delete p;
+}
+size_t blsbn254_g2prepared_count(const blsbn254_g2prepared* p) { return p ? p->u : 0; }
+// key validity (on curve, not the identity, in the r-torsion) of every prepared key, as a bitmap
+int blsbn254_g2prepared_valid(blsbn254_ctx* c, const blsbn254_g2prepared* p, uint8_t* ok_bitmap) {
+  if (!c || !p || p->ctx != c || (p->u && !ok_bitmap)) return BLSBN254_E_ARG;
+  if (!p->u) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  HIPCHK(c, c->bitmap.reserve((p->u + 7) / 8 + 8));
+  LAUNCH(c, "pack_bitmap", k_pack_bitmap, p->u, (const uint8_t*)p->ok.p, p->u, (uint8_t*)c->bitmap.p);
+  HIPCHK(c, hipMemcpyAsync(ok_bitmap, c->bitmap.p, (p->u + 7) / 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+int blsbn254_verify_batch_prepared(blsbn254_ctx* c, const blsbn254_g2prepared* keys, const uint32_t* key_idx, const uint8_t* msgs, const uint64_t* off,
+                                   const uint8_t* sigs, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* bm) {
+  if (!c || !keys || keys->ctx != c || !off || (n && (!key_idx || !sigs || !bm)) || (dst_len && !dst)) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
+  if (rc) return rc;
+  rc = stage_msgs(c, msgs, off, n);
+  if (rc) return rc;
+  const size_t nb = (n + 7) / 8;
+  HIPCHK(c, c->in_b.reserve(64 * n)); HIPCHK(c, c->kd_kid.reserve(4 * n)); HIPCHK(c, c->bitmap.reserve(nb + 8));
+  HIPCHK(c, hipMemcpyAsync(c->in_b.p, sigs, 64 * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->kd_kid.p, key_idx, 4 * n, hipMemcpyHostToDevice, c->stream));
+  for (size_t lo = 0; lo < n; lo += c->chunk) {
+    size_t m = n - lo < c->chunk ? n - lo : c->chunk;
+    rc = verify_prepared_dev(c, (const int32_t*)keys->table.p, (const uint8_t*)keys->ok.p, keys->u, (const uint32_t*)c->kd_kid.p + lo, false,
+                             (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p + lo, (const uint8_t*)c->in_b.p + 64 * lo, m, dl, (uint8_t*)c->bitmap.p + lo / 8, false);
+    if (rc) return rc;
+  }
+  HIPCHK(c, hipMemcpyAsync(bm, c->bitmap.p, nb, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+// how many verify chunks took the prepared-key path / the exact per-tuple path on this context (tests, bench)
+int blsbn254_path_stats(blsbn254_ctx* c, uint64_t out[2]) {
+  if (!c || !out) return BLSBN254_E_ARG;
+  out[0] = c->stat_prepared_chunks; out[1] = c->stat_exact_chunks;
+  return 0;
+}
+int blsbn254_set_auto_prepare(blsbn254_ctx* c, int on) { if (!c) return BLSBN254_E_ARG; c->auto_prepare = on != 0; return 0; }
+
 // ---------------- random-linear-combination batch verification
 static const size_t RLC_GROUP = 16;      // tuples per shared final exponentiation (power of two)
 int blsbn254_verify_batch_rlc(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs,

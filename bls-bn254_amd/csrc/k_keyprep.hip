@@ -1,0 +1,106 @@
+// k_keyprep.hip -- public-key side of the prepared-key verify path (G2Prepared, pairings.rs:609-660):
+//   * de-duplication of the batch's public keys (a batch of validator signatures repeats few keys: the synthetic workload of
+//     SURVEY.md 8d draws 262144 tuples from a pool of 1024): open-addressing hash table over the 128-byte encodings with a
+//     FULL comparison on every hit (a hash collision can never merge two different keys), per-key ids, key-sorted order;
+//   * k_g2_prepare: once per DISTINCT key -- decode, on-curve, psi subgroup test, and the 88 line coefficient triples of the
+//     optimal ate loop written as a table (g2_prepare_lines, pairing.h);
+//   * the small kernels that carry validity back from key-sorted order to the caller's order.
+// Own translation unit, tower / curve functions force-inlined.
+#include "lane_ops.h"
+#include "kernels.h"
+using namespace bn;
+
+namespace {
+__device__ inline uint32_t load_u32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+__device__ inline uint32_t key_hash(const uint8_t* pk, uint32_t seed) {
+  uint32_t h = seed ^ 0x9e3779b9u;
+  for (int k = 0; k < 32; ++k) { h ^= load_u32(pk + 4 * k); h *= 0x01000193u; h = (h << 13) | (h >> 19); }
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+__device__ inline bool key_equal(const uint8_t* a, const uint8_t* b) {
+  uint32_t d = 0;
+  for (int k = 0; k < 32; ++k) d |= load_u32(a + 4 * k) ^ load_u32(b + 4 * k);
+  return d == 0;
+}
+}  // namespace
+
+// rep[i] = index of the first-inserted tuple whose public key has the same 128 bytes.  slots: M = 2^log2m entries, all 0xffffffff.
+__global__ void k_kd_insert(const uint8_t* pks, uint32_t n, uint32_t* slots, uint32_t mask, uint32_t seed, uint32_t* rep) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* mine = pks + 128 * (size_t)i;
+  uint32_t s = key_hash(mine, seed) & mask;
+  for (;;) {                                             // terminates: the table has at least 2n slots
+    uint32_t old = atomicCAS(&slots[s], 0xffffffffu, i);
+    if (old == 0xffffffffu) { rep[i] = i; return; }
+    if (key_equal(mine, pks + 128 * (size_t)old)) { rep[i] = old; return; }
+    s = (s + 1) & mask;
+  }
+}
+// representatives take consecutive key ids (order of arrival; results do not depend on it); keys[id] = representative tuple
+__global__ void k_kd_assign(const uint32_t* rep, uint32_t n, uint32_t* kid, uint32_t* counter, uint32_t* keys) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || rep[i] != i) return;
+  uint32_t id = atomicAdd(counter, 1u);
+  kid[i] = id; keys[id] = i;
+}
+__global__ void k_kd_propagate(const uint32_t* rep, uint32_t n, uint32_t* kid, uint32_t* hist) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t id = kid[rep[i]];
+  kid[i] = id;
+  atomicAdd(&hist[id], 1u);
+}
+// histogram over explicit key indices (the G2Prepared API: the caller names the key of every tuple); bad = an index >= u
+__global__ void k_kd_hist(const uint32_t* kid, uint32_t n, uint32_t u, uint32_t* hist, int* bad) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (kid[i] >= u) { atomicMin(bad, (int)(i > 0x7ffffffeu ? 0x7ffffffeu : i)); return; }
+  atomicAdd(&hist[kid[i]], 1u);
+}
+// exclusive prefix sum of hist[0..u) into cursor[0..u): one workgroup, each thread a contiguous slice
+__global__ void __launch_bounds__(1024) k_scan_excl(const uint32_t* hist, uint32_t u, uint32_t* cursor) {
+  __shared__ uint32_t part[1024];
+  const uint32_t t = threadIdx.x, per = (u + 1023) / 1024, lo = t * per, hi = (lo + per < u) ? lo + per : u;
+  uint32_t s = 0;
+  for (uint32_t k = lo; k < hi; ++k) s += hist[k];
+  part[t] = s;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = t ? part[t - 1] : 0;
+  for (uint32_t k = lo; k < hi; ++k) { cursor[k] = run; run += hist[k]; }
+}
+__global__ void k_kd_scatter(const uint32_t* kid, uint32_t n, uint32_t u, uint32_t* cursor, uint32_t* perm) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || kid[i] >= u) return;
+  perm[atomicAdd(&cursor[kid[i]], 1u)] = i;
+}
+// lines + validity of u keys.  keys == NULL: key k is pks[128 k]; else key k is the public key of tuple keys[k].
+// table: u x 88 x 54 limbs, key-major contiguous.
+BN_KERNEL k_g2_prepare(const uint8_t* pks, const uint32_t* keys, uint32_t u, int32_t* table, uint8_t* key_ok) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= u) return;
+  const uint8_t* b = pks + 128 * (size_t)(keys ? keys[k] : k);
+  bool okd;
+  G2A q = g2_decode(b, okd);
+  const bool ok = okd & !q.inf & g2_on_curve(q) & g2_torsion_free(q);
+  q.x = fp2_select(ok, q.x, fp2_const(bnc::G2_GEN_X)); q.y = fp2_select(ok, q.y, fp2_const(bnc::G2_GEN_Y)); q.inf = false;
+  g2_prepare_lines(q, Ws{table, 1, k * (uint32_t)(BN_NEG_G2_LINES * 54 * 4), true});
+  key_ok[k] = ok ? 1 : 0;
+}
+// valid (caller's order, one byte per tuple) from the key-sorted results: is_one[s] & flags[s] of sorted position s = perm^-1
+__global__ void k_prep_unsort(const uint8_t* is_one, const uint8_t* flags, const uint32_t* perm, uint32_t n, uint8_t* valid) {
+  uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  valid[perm[s]] = (is_one[s] != 0 && flags[s] != 0) ? 1 : 0;
+}
+__global__ void __launch_bounds__(256) k_pack_bitmap(const uint8_t* valid, size_t n, uint8_t* bitmap) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  write_ballot(bitmap, n, i, i < n && valid[i] != 0);
+}

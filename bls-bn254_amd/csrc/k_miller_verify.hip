@@ -12,7 +12,11 @@
 using namespace bn;
 
 BN_KERNEL k_miller_verify(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n, int32_t* f_ws, uint8_t* flags) {
-  __shared__ int32_t inv_lds[72 * 256];          // each lane touches only its own column: no barrier needed
+#ifdef BN_VERIFY_PARK_T
+  __shared__ int32_t inv_lds[126 * 256];         // + 54 limbs: the parked running point
+#else
+  __shared__ int32_t inv_lds[72 * 256];
+#endif          // each lane touches only its own column: no barrier needed
   // 32-bit lane index and buffer-addressed workspaces: no 64-bit per-lane value lives across the loop (a
   // zero-extended thread id did, and its zero half was re-loaded from scratch wherever a zero was needed)
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -63,6 +63,17 @@ BN_KERNEL k_rlc_gather(const uint32_t* idx, size_t m, const uint8_t* pks, const 
 BN_KERNEL k_field_op(int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status);
 BN_KERNEL k_gt_pow(const uint8_t* gt, const uint8_t* scalars, size_t n, uint8_t* out, uint8_t* status);
 BN_KERNEL k_fr_decode(const uint8_t* ids, size_t t, int32_t* x_ws, uint8_t* status);
+__global__ void k_kd_insert(const uint8_t* pks, uint32_t n, uint32_t* slots, uint32_t mask, uint32_t seed, uint32_t* rep);
+__global__ void k_kd_assign(const uint32_t* rep, uint32_t n, uint32_t* kid, uint32_t* counter, uint32_t* keys);
+__global__ void k_kd_propagate(const uint32_t* rep, uint32_t n, uint32_t* kid, uint32_t* hist);
+__global__ void k_kd_hist(const uint32_t* kid, uint32_t n, uint32_t u, uint32_t* hist, int* bad);
+__global__ void __launch_bounds__(1024) k_scan_excl(const uint32_t* hist, uint32_t u, uint32_t* cursor);
+__global__ void k_kd_scatter(const uint32_t* kid, uint32_t n, uint32_t u, uint32_t* cursor, uint32_t* perm);
+BN_KERNEL k_g2_prepare(const uint8_t* pks, const uint32_t* keys, uint32_t u, int32_t* table, uint8_t* key_ok);
+__global__ void k_prep_unsort(const uint8_t* is_one, const uint8_t* flags, const uint32_t* perm, uint32_t n, uint8_t* valid);
+__global__ void __launch_bounds__(256) k_pack_bitmap(const uint8_t* valid, size_t n, uint8_t* bitmap);
+BN_KERNEL k_miller_prepared(const uint32_t* perm, const uint32_t* kid, const uint8_t* sigs, const int32_t* h_ws, size_t h_stride,
+                            const int32_t* table, const uint8_t* key_ok, size_t n, int32_t* f_ws, uint8_t* flags);
 BN_KERNEL k_lagrange_partial(const int32_t* x_ws, size_t t, size_t J, int32_t* pnum, int32_t* pden, uint8_t* dup);
 BN_KERNEL k_lagrange_finish(const int32_t* pnum, const int32_t* pden, size_t t, size_t S, uint8_t* scalars, uint32_t* glv_ws);
 BN_KERNEL k_msm_window(const uint8_t* g1, const uint32_t* glv_ws, size_t t, int32_t* part, uint8_t* status);

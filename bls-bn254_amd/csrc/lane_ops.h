@@ -92,7 +92,11 @@ BN_FUNC Fp12 lane_miller_verify_ws(const uint8_t* pk_b, const uint8_t* sig_b, co
   fp2_store_mem(ws_at(inv, 36), fp2_norm(fp2_select(pk_ok, pk.x, fp2_const(bnc::G2_GEN_X))));
   fp2_store_mem(ws_at(inv, 54), fp2_norm(fp2_select(pk_ok, pk.y, fp2_const(bnc::G2_GEN_Y))));
   BN_MEM_FENCE;
+#ifdef BN_VERIFY_PARK_T
+  return miller_loop_verify_ws2(inv, ws_at(inv, 72), table);
+#else
   return miller_loop_verify_ws(inv, table);
+#endif
 }
 BN_FUNC Fp12 lane_miller_verify(const uint8_t* pk_b, const uint8_t* sig_b, const G1A& h,
                                      const int32_t (*table)[54], uint8_t& flags) {

@@ -198,6 +198,57 @@ BN_FUNC Fp12 miller_loop_verify_ws(const Ws& inv, const int32_t (*table)[54]) {
   return f;
 }
 
+BN_INL void g2j_store(const Ws& w, const G2J& t) { fp2_store_mem(w, t.x); fp2_store_mem(ws_at(w, 18), t.y); fp2_store_mem(ws_at(w, 36), t.z); }
+BN_INL G2J g2j_load(const Ws& w) { return {fp2_load_mem(w), fp2_load_mem(ws_at(w, 18)), fp2_load_mem(ws_at(w, 36))}; }
+// The verify loop with the running point T ALSO parked: T sits in `park` (LDS, 54 limbs) except while its line step runs,
+// so that neither the squaring of f nor the two-line product has to hold it (the same scheme as the two-pair loop below).
+BN_FUNC Fp12 miller_loop_verify_ws2(const Ws& inv, const Ws& park_in, const int32_t (*table)[54]) {
+  Fp12 f = fp12_one();
+  Ws p = inv, park = park_in;
+  fp2_store_mem(park, fp2_load_mem(ws_at(inv, 36))); fp2_store_mem(ws_at(park, 18), fp2_load_mem(ws_at(inv, 54))); fp2_store_mem(ws_at(park, 36), fp2_one());
+  BN_MEM_FENCE;
+  int ti = 0;
+  for (int j = bnc::ATE_NAF_LEN - 2; j >= 0; --j) {
+    f = fp12_sqr(f);
+    BN_OPAQUE(p); BN_OPAQUE(park);
+    Fp sx = fp_load_mem(p), sy = fp_load_mem(ws_at(p, 9)), hx = fp_load_mem(ws_at(p, 18)), hy = fp_load_mem(ws_at(p, 27));
+    G2J T = g2j_load(park);
+    BN_SCHED_BARRIER;
+    Line l = doubling_step(T);
+    g2j_store(park, T);
+    BN_MEM_FENCE;
+    f = ell2(f, line_from_table(table[ti++]), sx, sy, l, hx, hy);
+    int d = ate_naf_digit(j);
+    if (d != 0) {
+      BN_OPAQUE(p); BN_OPAQUE(park);
+      Fp2 qy = fp2_load_mem(ws_at(p, 54));
+      Fp2 nqy = fp2_norm(fp2_neg(qy));
+      Fp2 qx = fp2_load_mem(ws_at(p, 36));
+      sx = fp_load_mem(p); sy = fp_load_mem(ws_at(p, 9)); hx = fp_load_mem(ws_at(p, 18)); hy = fp_load_mem(ws_at(p, 27));
+      T = g2j_load(park);
+      BN_SCHED_BARRIER;
+      l = addition_step(T, qx, fp2_select(d > 0, qy, nqy));
+      g2j_store(park, T);
+      BN_MEM_FENCE;
+      f = ell2(f, line_from_table(table[ti++]), sx, sy, l, hx, hy);
+    }
+  }
+  BN_OPAQUE(p); BN_OPAQUE(park);
+  Fp2 g2 = fp2_const(bnc::GAMMA1[1]), g3 = fp2_const(bnc::GAMMA1[2]);
+  Fp2 q1x = fp2_mul(fp2_norm(fp2_conj(fp2_load_mem(ws_at(p, 36)))), g2);
+  Fp2 q1y = fp2_mul(fp2_norm(fp2_conj(fp2_load_mem(ws_at(p, 54)))), g3);
+  Fp2 q2x = fp2_mul(fp2_norm(fp2_conj(q1x)), g2);
+  Fp2 q2y = fp2_norm(fp2_neg(fp2_mul(fp2_norm(fp2_conj(q1y)), g3)));
+  G2J T = g2j_load(park);
+  Line l = addition_step(T, q1x, q1y);
+  BN_OPAQUE(p);
+  f = ell2(f, line_from_table(table[ti++]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)), l, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
+  l = addition_step(T, q2x, q2y);
+  BN_OPAQUE(p);
+  f = ell2(f, line_from_table(table[ti++]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)), l, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
+  return f;
+}
+
 // Two VARIABLE pairs per lane sharing one f^2 per digit (multi_miller_loop, pairings.rs:808-857: "one shared f.square()
 // per bit for all terms"): f = ML(Ha, Qa) * ML(Hb, Qb), bit-identical to the product of the two one-pair loops because the
 // arithmetic is exact.  Used by aggregate verify (k_miller_hpk2.hip).  Register budget = that of the verify loop: only ONE
@@ -205,8 +256,6 @@ BN_FUNC Fp12 miller_loop_verify_ws(const Ws& inv, const int32_t (*table)[54]) {
 // in `lpark` (LDS, 54 limbs) while the second is computed.  `hh` (LDS) holds Ha.x, Ha.y, Hb.x, Hb.y (9 limbs each); `qw`
 // (HBM workspace, limb-major) holds Qa.x, Qa.y, Qb.x, Qb.y (18 limbs each), read in the addition steps only.
 // live_a / live_b: a pair that is padding (odd count) or failed validation contributes the line 1, i.e. nothing.
-BN_INL void g2j_store(const Ws& w, const G2J& t) { fp2_store_mem(w, t.x); fp2_store_mem(ws_at(w, 18), t.y); fp2_store_mem(ws_at(w, 36), t.z); }
-BN_INL G2J g2j_load(const Ws& w) { return {fp2_load_mem(w), fp2_load_mem(ws_at(w, 18)), fp2_load_mem(ws_at(w, 36))}; }
 BN_INL void line_store(const Ws& w, const Line& l) { fp2_store_mem(w, l.c0); fp2_store_mem(ws_at(w, 18), l.c1); fp2_store_mem(ws_at(w, 36), l.c2); }
 BN_INL Line line_load(const Ws& w) { return {fp2_load_mem(w), fp2_load_mem(ws_at(w, 18)), fp2_load_mem(ws_at(w, 36))}; }
 BN_INL Line line_mask(bool live, const Line& l) {               // live ? l : the constant line 1
@@ -442,6 +491,60 @@ BN_FUNC void fe_h2_tail(const Fp12& x0, const Ws& b_in, const Ws& c_out, const W
   fp12_store_mem(b2_out, fp12_conj(fp12_mul_mem(x0, b_in, park)));                        // b2 = c conj(b) = conj(x0 b)
   BN_MEM_FENCE;
   fp12_store_mem(d2_out, fp12_cyclotomic_sqr(fp12_load_mem(c_out)));                      // d2 = c^2
+}
+
+// G2Prepared (pairings.rs:609-660, :726-757; E6: the loop pushes 88 coefficients, the reference's array holds 68): the 88
+// line coefficient triples of the optimal ate loop for ONE public key, in evaluation order, as canonical Montgomery limbs
+// (54 per line).  g2_prepare_lines writes them; miller_loop_prepared consumes them next to the fixed -G2gen table, so a
+// verify for a known key runs no point arithmetic at all: f <- f^2 * l_sig * l_key per step.
+BN_INL void line_store_limbs(const Ws& w, const Line& l) { fp2_store_limbs(w, l.c0); fp2_store_limbs(ws_at(w, 18), l.c1); fp2_store_limbs(ws_at(w, 36), l.c2); }
+BN_INL Line line_load_limbs(const Ws& w) { return {fp2_load_limbs(w), fp2_load_limbs(ws_at(w, 18)), fp2_load_limbs(ws_at(w, 36))}; }
+BN_FUNC void g2_prepare_lines(const G2A& q, const Ws& out) {
+  BN_CTX;
+  G2J T = {q.x, q.y, fp2_one()};
+  Fp2 nqy = fp2_norm(fp2_neg(q.y));
+  int ti = 0;
+  for (int j = bnc::ATE_NAF_LEN - 2; j >= 0; --j) {
+    line_store_limbs(ws_at(out, 54 * (size_t)ti++), doubling_step(T));
+    int d = ate_naf_digit(j);
+    if (d != 0) line_store_limbs(ws_at(out, 54 * (size_t)ti++), addition_step(T, q.x, d > 0 ? q.y : nqy));
+  }
+  Fp2 g2 = fp2_const(bnc::GAMMA1[1]), g3 = fp2_const(bnc::GAMMA1[2]);
+  Fp2 q1x = fp2_mul(fp2_norm(fp2_conj(q.x)), g2), q1y = fp2_mul(fp2_norm(fp2_conj(q.y)), g3);
+  Fp2 q2x = fp2_mul(fp2_norm(fp2_conj(q1x)), g2);
+  Fp2 q2y = fp2_norm(fp2_neg(fp2_mul(fp2_norm(fp2_conj(q1y)), g3)));
+  line_store_limbs(ws_at(out, 54 * (size_t)ti++), addition_step(T, q1x, q1y));
+  line_store_limbs(ws_at(out, 54 * (size_t)ti++), addition_step(T, q2x, q2y));
+}
+// f = ML(sig, -G2gen) * ML(H, pk) with BOTH pairs' lines read from tables: `table` the generated -G2gen lines (wave-uniform
+// address), `ktab` this lane's key (per-lane base; waves are key-sorted, so the 64 lanes mostly read one address).
+// inv (LDS): sig.x, sig.y, H.x, H.y, 9 limbs each.  The key line of a step is fetched before the squaring that hides it.
+BN_FUNC Fp12 miller_loop_prepared(const Ws& inv, const int32_t (*table)[54], const Ws& ktab_in) {
+  Fp12 f = fp12_one();
+  Ws p = inv, kt = ktab_in;
+  int ti = 0;
+  for (int j = bnc::ATE_NAF_LEN - 2; j >= 0; --j) {
+    BN_OPAQUE(kt);
+    Line lk = line_load_limbs(ws_at(kt, 54 * (size_t)ti));
+    BN_SCHED_BARRIER;
+    f = fp12_sqr(f);
+    BN_OPAQUE(p);
+    f = ell2(f, line_from_table(table[ti]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)), lk, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
+    ++ti;
+    if (ate_naf_digit(j) != 0) {
+      BN_OPAQUE(kt); BN_OPAQUE(p);
+      lk = line_load_limbs(ws_at(kt, 54 * (size_t)ti));
+      f = ell2(f, line_from_table(table[ti]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)), lk, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
+      ++ti;
+    }
+  }
+  for (int e = 0; e < 2; ++e) {
+    BN_OPAQUE(kt); BN_OPAQUE(p);
+    Line lk = line_load_limbs(ws_at(kt, 54 * (size_t)ti));
+    f = ell2(f, line_from_table(table[ti]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)), lk, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
+    ++ti;
+  }
+  return f;
 }
 
 }  // namespace bn

@@ -192,6 +192,33 @@ class Engine:
                                                   ctypes.c_size_t(len(dst)), po))
         return o[:(n + 7) // 8].tobytes()
 
+    def set_auto_prepare(self, on):
+        """verify_batch's automatic key de-duplication + per-key preparation (default on); off = exact per-tuple path."""
+        self._chk(self._lib.blsbn254_set_auto_prepare(self._ctx, ctypes.c_int(1 if on else 0)))
+
+    def path_stats(self):
+        """(chunks served by the prepared-key path, chunks served by the exact per-tuple path)"""
+        o = (ctypes.c_uint64 * 2)()
+        self._chk(self._lib.blsbn254_path_stats(self._ctx, o))
+        return int(o[0]), int(o[1])
+
+    def g2_prepare_batch(self, pks, u):
+        """G2Prepared::from (pairings.rs:609-660) for u keys: a device-resident table handle (PreparedKeys)."""
+        return PreparedKeys(self, pks, u)
+
+    def verify_batch_prepared(self, keys, key_idx, msgs, sigs, dst=DEFAULT_DST):
+        n = len(msgs)
+        data, off = pack_messages(msgs)
+        idx = np.ascontiguousarray(np.asarray(key_idx, dtype=np.uint32))
+        if idx.size != n:
+            raise ValueError("one key index per tuple")
+        if idx.size == 0:
+            idx = np.zeros(1, dtype=np.uint32)
+        m, pm = _inbuf(data); s, ps = _inbuf(sigs, 64 * n); d, pd = _inbuf(dst); o, po = _outbuf((n + 7) // 8)
+        self._chk(self._lib.blsbn254_verify_batch_prepared(self._ctx, keys._h, idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), pm,
+                                                           off.ctypes.data_as(_u64p), ps, ctypes.c_size_t(n), pd, ctypes.c_size_t(len(dst)), po))
+        return o[:(n + 7) // 8].tobytes()
+
     def verify_batch_rlc(self, pks, msgs, sigs, dst=DEFAULT_DST, seed=None):
         """Same bitmap as verify_batch, via random linear combinations (one final exponentiation per 16 tuples,
         exact re-verification of failing groups).  seed = None: the library draws it from the OS inside the call
@@ -390,6 +417,38 @@ class Engine:
             nm = names.raw[32 * i:32 * i + 32].split(b"\0")[0].decode()
             out[nm] = {"launches": int(launches[i]), "total_ms": float(ms[i])}
         return out
+
+
+class PreparedKeys:
+    """blsbn254_g2prepared: the line tables of u public keys, resident on the engine's GPU."""
+
+    def __init__(self, engine, pks, u):
+        self._eng = engine
+        self._lib = engine._lib
+        self._lib.blsbn254_g2prepared_count.restype = ctypes.c_size_t
+        self._h = ctypes.c_void_p()
+        a, pa = _inbuf(pks, 128 * u)
+        engine._chk(self._lib.blsbn254_g2_prepare_batch(engine._ctx, pa, ctypes.c_size_t(u), ctypes.byref(self._h)))
+
+    def count(self):
+        return int(self._lib.blsbn254_g2prepared_count(self._h))
+
+    def valid_bitmap(self):
+        u = self.count()
+        o, po = _outbuf((u + 7) // 8)
+        self._eng._chk(self._lib.blsbn254_g2prepared_valid(self._eng._ctx, self._h, po))
+        return o[:(u + 7) // 8].tobytes()
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self._eng, "_ctx", None):
+            self._lib.blsbn254_g2prepared_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class MultiEngine:

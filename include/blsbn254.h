@@ -101,6 +101,26 @@ int blsbn254_verify_batch(blsbn254_ctx* ctx, const uint8_t* pks, const uint8_t* 
  * The library does not detect duplicate messages (the reference has no BLS layer to pin either behaviour). */
 int blsbn254_aggregate_verify(blsbn254_ctx* ctx, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
                               const uint8_t agg_sig[64], const uint8_t* dst, size_t dst_len, int* valid);
+/* Repeated signers.  blsbn254_verify_batch (and _dev) de-duplicates the public keys of a batch on the GPU (hash table over
+ * the 128-byte encodings, full comparison on every hit) and, when at most half of them are distinct (and at most 65536),
+ * validates each DISTINCT key once and turns it into its table of 88 line-coefficient triples -- G2Prepared::from,
+ * pairings.rs:609-660 (E6: 88 entries, not 68) -- beside hash-to-G1; the tuples then run a table-only Miller loop
+ * (multi_miller_loop over prepared terms, pairings.rs:808-857) in key-sorted order.  Same bitmap as the exact
+ * per-tuple path, which batches of mostly distinct keys keep taking.  BLSBN254_AUTO_PREPARE=0 in the environment or
+ * blsbn254_set_auto_prepare(ctx, 0) forces the exact path; blsbn254_path_stats counts the chunks each path served. */
+int blsbn254_set_auto_prepare(blsbn254_ctx* ctx, int on);
+int blsbn254_path_stats(blsbn254_ctx* ctx, uint64_t out[2] /* prepared, exact */);
+/* The explicit form: prepare u keys once (device-resident, owned by the handle, tied to ctx), then verify any number of
+ * batches against them, naming the key of every tuple by its index (key_idx[i] < u, else BLSBN254_E_ARG).  A key that
+ * does not decode, is the identity, is off the curve or outside the r-torsion makes its tuples invalid (bit cleared). */
+typedef struct blsbn254_g2prepared blsbn254_g2prepared;
+int blsbn254_g2_prepare_batch(blsbn254_ctx* ctx, const uint8_t* pks /* u*128 */, size_t u, blsbn254_g2prepared** out);
+void blsbn254_g2prepared_destroy(blsbn254_g2prepared* keys);
+size_t blsbn254_g2prepared_count(const blsbn254_g2prepared* keys);
+int blsbn254_g2prepared_valid(blsbn254_ctx* ctx, const blsbn254_g2prepared* keys, uint8_t* ok_bitmap /* ceil(u/8) */);
+int blsbn254_verify_batch_prepared(blsbn254_ctx* ctx, const blsbn254_g2prepared* keys, const uint32_t* key_idx,
+                                   const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, size_t n,
+                                   const uint8_t* dst, size_t dst_len, uint8_t* valid_bitmap);
 /* The same check split for sharding over GPUs: every rank reduces ITS (pk_i, msg_i) to one
  * Fp12 partial product prod_i ML(H(msg_i), pk_i) (384 B; n = 0 gives Fp12::ONE) and reports whether all its
  * public keys validated; the partials are exchanged (all-gather of 384-byte records, Fp12 multiplication is

@@ -593,3 +593,99 @@ def test_threshold_combine_sizes_and_lagrange(eng, oracle, pyref, M, t):
             eng.threshold_combine(idb[:32 * (t - 1)] + idb[:32], parts, t)              # last id repeats the first
         with pytest.raises(M.InvalidG1Bytes):
             eng.threshold_combine(idb, parts[:64 * (t - 1)] + b"\xff" * 64, t)          # undecodable partial signature
+
+
+def _mixed_batch(oracle, n, dst, pool, seed):
+    """n tuples over `pool` honest keys plus bad keys (outside the subgroup, undecodable, identity) and every kind of bad
+    signature / message; returns (pks, msgs, sigs, expected bools)."""
+    rnd = random.Random(seed)
+    sks = [synth.sk_of(k) for k in range(pool)]
+    pkp = [oracle.sk_to_pk(s) for s in sks]
+    uniq = min(n, 96)
+    base = []
+    for i in range(uniq):
+        m = synth.msg_of(1000 * seed + i) + bytes(i % 5)
+        base.append((i % pool, m, oracle.sign(sks[i % pool], m, dst)))
+    g1 = oracle.g1_generator()
+    pks, msgs, sigs, exp = [], [], [], []
+    for i in range(n):
+        k, m, s = base[rnd.randrange(uniq)]
+        pk, ok, kind = pkp[k], True, rnd.randrange(24)
+        if kind == 0: m, ok = m + b"!", False
+        elif kind == 1: s, ok = oracle.g1_add(s, g1), False
+        elif kind == 2: pk, ok = pkp[(k + 1) % pool], pool == 1
+        elif kind == 3: s, ok = s[:63] + bytes([s[63] ^ 1]), False
+        elif kind == 4: pk, ok = synth.NON_SUBGROUP_PK, False
+        elif kind == 5: pk, ok = b"\xff" * 32 + pk[32:], False
+        elif kind == 6: pk, ok = IDENT2, False
+        elif kind == 7: s, ok = IDENT1, False
+        pks.append(pk); msgs.append(m); sigs.append(s); exp.append(ok)
+    return b"".join(pks), msgs, b"".join(sigs), exp
+
+
+@pytest.mark.parametrize("n,pool", [(1024, 1), (1500, 7), (4096, 64), (20000, 300)])
+def test_prepared_key_path_equals_exact_path(eng, oracle, M, n, pool):
+    """verify_batch with the automatic key de-duplication + per-key line tables (G2Prepared, pairings.rs:609-660) against
+    the exact per-tuple path and the oracle: same bitmap on batches that mix honest repeated keys with keys outside the
+    subgroup, undecodable keys, the identity key, and every kind of bad signature and message."""
+    dst = M.DEFAULT_DST
+    pks, msgs, sigs, exp = _mixed_batch(oracle, n, dst, pool, seed=n)
+    want = synth.bitmap_of(exp)
+    p0, e0 = eng.path_stats()
+    eng.set_auto_prepare(True)
+    got_prep = eng.verify_batch(pks, msgs, sigs, dst)
+    p1, e1 = eng.path_stats()
+    eng.set_auto_prepare(False)
+    got_exact = eng.verify_batch(pks, msgs, sigs, dst)
+    p2, e2 = eng.path_stats()
+    eng.set_auto_prepare(True)
+    assert p1 == p0 + 1 and e1 == e0 and p2 == p1 and e2 == e1 + 1          # each call really took the path it names
+    assert got_exact == want and got_prep == want
+    if n <= 4096:
+        assert oracle.verify_batch(pks, msgs, sigs, dst, nthreads=8) == want
+
+
+def test_prepared_path_not_taken_for_distinct_keys(eng, oracle, M):
+    """mostly distinct keys: the de-duplication finds more than n / 2 of them and the exact path runs"""
+    dst = M.DEFAULT_DST
+    n = 1100
+    sks = [synth.sk_of(k) for k in range(n)]
+    pks = eng.sk_to_pk_batch(b"".join(s.to_bytes(32, "big") for s in sks), n)
+    msgs = [synth.msg_of(i) for i in range(n)]
+    sigs = eng.sign_batch(b"".join(s.to_bytes(32, "big") for s in sks), msgs, dst)
+    p0, e0 = eng.path_stats()
+    bm = eng.verify_batch(pks, msgs, sigs, dst)
+    assert eng.path_stats() == (p0, e0 + 1) and bm == synth.bitmap_of([True] * n)
+
+
+def test_explicit_g2prepared_api(eng, oracle, M):
+    """blsbn254_g2_prepare_batch + blsbn254_verify_batch_prepared: keys prepared once, batches verified by key index"""
+    dst = M.DEFAULT_DST
+    pool = 5
+    sks = [synth.sk_of(k) for k in range(pool)]
+    keys = [oracle.sk_to_pk(s) for s in sks] + [synth.NON_SUBGROUP_PK, IDENT2, b"\xff" * 128]
+    prep = eng.g2_prepare_batch(b"".join(keys), len(keys))
+    assert prep.count() == 8 and prep.valid_bitmap() == bytes([0b00011111])
+    rnd = random.Random(3)
+    n = 333
+    idx, msgs, sigs, exp = [], [], [], []
+    for i in range(n):
+        k = rnd.randrange(len(keys))
+        m = synth.msg_of(i)
+        signer = k if k < pool else 0
+        s = oracle.sign(sks[signer], m, dst) if i < 40 or i % 7 == 0 else None
+        ok = k < pool
+        if s is None:                       # reuse an early tuple as it is (valid or not)
+            j = rnd.randrange(min(i, 40))
+            k, m, s, ok = idx[j], msgs[j], sigs[j], exp[j]
+        if i % 11 == 3:
+            m, ok = m + b"x", False
+        idx.append(k); msgs.append(m); sigs.append(s); exp.append(ok)
+    got = eng.verify_batch_prepared(prep, idx, msgs, b"".join(sigs), dst)
+    assert got == synth.bitmap_of(exp)
+    assert got == eng.verify_batch(b"".join(keys[k] for k in idx), msgs, b"".join(sigs), dst)
+    assert eng.verify_batch_prepared(prep, [], [], b"", dst) == b""
+    with pytest.raises(M.Bn254Error) as e:
+        eng.verify_batch_prepared(prep, [0, 8], msgs[:2], b"".join(sigs[:2]), dst)          # key index out of range
+    assert e.value.code == -1
+    prep.close()
