@@ -172,15 +172,15 @@ BN_INL Fp fp_norm(const Fp& a) {
   return r;
 }
 
-// r = K1*x1 + K2*x2 (+ K3*x3), normalised like fp_norm.  |Ki| small compile-time integers.
+// r = K1*x1 + K2*x2 (+ K3*x3 + K4*x4), normalised like fp_norm.  |Ki| small compile-time integers.
 // 64-bit per-limb sums (v_mad_i64_i32 with an inline constant), then one parallel carry.
 // When the coefficients are large (REDUCE) the value is also brought back to (-eps*p, (1+eps)*p):
 // q = floor(value / p) is estimated from the top limbs (value / 2^232 = top + O(sum|Ki|)), and -q*p is
 // folded into the same per-limb sums.  Without it the xi-multiplications (x10) would outgrow the
 // Montgomery contraction (p / 2^261 = 1/168) and the top limb would eventually overflow.
 constexpr int lc_abs(int k) { return k < 0 ? -k : k; }
-template <int K1, int K2, int K3, bool REDUCE = (lc_abs(K1) + lc_abs(K2) + lc_abs(K3) > 4)>
-BN_INL Fp fp_lc3(const Fp& x1, const Fp& x2, const Fp& x3) {
+template <int K1, int K2, int K3, int K4, bool REDUCE = (lc_abs(K1) + lc_abs(K2) + lc_abs(K3) + lc_abs(K4) > 4)>
+BN_INL Fp fp_lc4(const Fp& x1, const Fp& x2, const Fp& x3, const Fp& x4) {
   Fp r;
   int32_t lo[NL], c[NL];
   int32_t q = 0;
@@ -189,26 +189,29 @@ BN_INL Fp fp_lc3(const Fp& x1, const Fp& x2, const Fp& x3) {
   // strength-reduces x * -2 or x * 1 into sign extension + 64-bit shift + subtract with borrow (5 instructions),
   // and zero-extends known-non-negative limbs with whatever register "is known to hold 0" (a spilled one, in the
   // Miller kernel: hundreds of scratch re-loads per iteration).
-  int32_t k1 = K1, k2 = K2, k3 = K3;
-  asm("; lc k1" : "+s"(k1)); asm("; lc k2" : "+s"(k2)); asm("; lc k3" : "+s"(k3));   // distinct texts: equal constants must not be merged, or x1*k + x2*k is refactored into a 64-bit (x1 + x2) * k
+  int32_t k1 = K1, k2 = K2, k3 = K3, k4 = K4;
+  asm("; lc k1" : "+s"(k1)); asm("; lc k2" : "+s"(k2)); asm("; lc k3" : "+s"(k3)); asm("; lc k4" : "+s"(k4));   // distinct texts: equal constants must not be merged, or x1*k + x2*k is refactored into a 64-bit (x1 + x2) * k
 #else
-  const int32_t k1 = K1, k2 = K2, k3 = K3;
+  const int32_t k1 = K1, k2 = K2, k3 = K3, k4 = K4;
 #endif
   if (REDUCE) {
     int64_t te = (int64_t)x1.l[NL - 1] * k1 + (int64_t)x2.l[NL - 1] * k2;
     if (K3 != 0) te += (int64_t)x3.l[NL - 1] * k3;
+    if (K4 != 0) te += (int64_t)x4.l[NL - 1] * k4;
     q = (int32_t)((te * bnc::LC_QINV) >> 52);
   }
   BN_UNROLL for (int i = 0; i < NL; ++i) {
-    const int32_t a1 = x1.l[i], a2 = x2.l[i], a3 = x3.l[i];
+    const int32_t a1 = x1.l[i], a2 = x2.l[i], a3 = x3.l[i], a4 = x4.l[i];
 #if defined(__HIP_DEVICE_COMPILE__) && defined(BN_LC_MAD)
     int64_t t = REDUCE ? -(int64_t)q * bnc::P[i] : 0;
+    if (K4 != 0) t += (int64_t)a4 * k4;
     if (K3 != 0) t += (int64_t)a3 * k3;
     t += (int64_t)a2 * k2;
     t += (int64_t)a1 * k1;
 #else
     int64_t t = (int64_t)a1 * K1 + (int64_t)a2 * K2;
     if (K3 != 0) t += (int64_t)a3 * K3;
+    if (K4 != 0) t += (int64_t)a4 * K4;
     if (REDUCE) t -= (int64_t)q * bnc::P[i];
 #endif
     lo[i] = (int32_t)((uint32_t)t & (uint32_t)MASK);
@@ -218,10 +221,10 @@ BN_INL Fp fp_lc3(const Fp& x1, const Fp& x2, const Fp& x3) {
   BN_UNROLL for (int i = 1; i < NL - 1; ++i) r.l[i] = lo[i] + c[i - 1];
   r.l[NL - 1] = lo[NL - 1] + c[NL - 2] + (c[NL - 1] << RB);     // top limb keeps everything above
   BN_TRK(++check_stats().lcs;
-         double a1 = lc_abs(K1), a2 = lc_abs(K2), a3 = lc_abs(K3);
-         double m = a1 * mag(x1) + a2 * mag(x2) + a3 * mag(x3);            // |t| / L before the q*p term
-         double vb = a1 * x1.vb + a2 * x2.vb + a3 * x3.vb;
-         double tin = a1 * tmag(x1) + a2 * tmag(x2) + a3 * tmag(x3);       // |te| / L
+         double a1 = lc_abs(K1), a2 = lc_abs(K2), a3 = lc_abs(K3), a4 = lc_abs(K4);
+         double m = a1 * mag(x1) + a2 * mag(x2) + a3 * mag(x3) + a4 * mag(x4);            // |t| / L before the q*p term
+         double vb = a1 * x1.vb + a2 * x2.vb + a3 * x3.vb + a4 * x4.vb;
+         double tin = a1 * tmag(x1) + a2 * tmag(x2) + a3 * tmag(x3) + a4 * tmag(x4);       // |te| / L
          if (tin >= 7.9) check_fail("fp_lc top-limb estimate: te * LC_QINV must fit 64 bits", tin);
          double mq = 0;
          if (REDUCE) { mq = vb + 1; m += mq; vb = 1.0 + (m + 4) / 3171406.0; }   // |q| <= vb + 1, |q p_i| <= mq L
@@ -231,6 +234,8 @@ BN_INL Fp fp_lc3(const Fp& x1, const Fp& x2, const Fp& x3) {
          set_trk(r, -(m + 1) / 536870912.0, 1.0 + (m + 1) / 536870912.0, -top, top, vb); check_actual(r, "fp_lc");)
   return r;
 }
+template <int K1, int K2, int K3>
+BN_INL Fp fp_lc3(const Fp& x1, const Fp& x2, const Fp& x3) { return fp_lc4<K1, K2, K3, 0>(x1, x2, x3, x1); }
 template <int K1, int K2>
 BN_INL Fp fp_lc2(const Fp& x1, const Fp& x2) { return fp_lc3<K1, K2, 0>(x1, x2, x1); }
 

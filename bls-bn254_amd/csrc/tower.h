@@ -288,30 +288,34 @@ BN_FUNC Fp12 fp12_frob(const Fp12& a) {
   return {{fp12_frob_coeff<K, 0>(a.c0.c0), fp12_frob_coeff<K, 2>(a.c0.c1), fp12_frob_coeff<K, 4>(a.c0.c2)},
           {fp12_frob_coeff<K, 1>(a.c1.c0), fp12_frob_coeff<K, 3>(a.c1.c1), fp12_frob_coeff<K, 5>(a.c1.c2)}};
 }
-BN_INL void fp4_square(Fp2& c0, Fp2& c1, const Fp2& a, const Fp2& b) {      // pairings.rs:52-63
-  Fp2 t0 = fp2_sqr(a), t1 = fp2_sqr(b);
-  c0 = fp2_add_mul_xi(t0, t1);
-  Fp2 s = fp2_sqr(fp2_norm(fp2_add(a, b)));                     // three squarings (2 x 162 MADs each) instead of a
-  c1 = fp2_norm(fp2_sub(fp2_sub(s, t0), t1));                   // product (486 MADs): 2ab = (a+b)^2 - a^2 - b^2
+// Granger-Scott squaring in the cyclotomic subgroup, pairings.rs:68-115 (valid with xi = 9+u).  Same values as
+//   fp4_square(t0, t1, z0, z1) ... ; z0' = 3 t0 - 2 z0 ; z1' = 3 t1 + 2 z1 ; ...
+// but the combination 3 (ta + xi tb) -+ 2 z of each output is ONE four-term pass over the raw squarings ta = a^2,
+// tb = b^2, s = (a + b)^2 -- three squarings (2 x 162 MADs each) instead of two squarings and a product (486 MADs) -- (fp_lc4) instead of fp4_square's (pairings.rs:52-63) own pass followed by a second one: 4 passes per Fp4 square
+// instead of 8 (a pass is ~60 instructions per Fp, about a quarter of a multiplication).
+struct Fp4Sq { Fp2 ta, tb, s; };
+BN_INL Fp4Sq fp4_sq_raw(const Fp2& a, const Fp2& b) { return {fp2_sqr(a), fp2_sqr(b), fp2_sqr(fp2_norm(fp2_add(a, b)))}; }
+// 3 (ta + xi tb) - 2 z
+BN_INL Fp2 cyc_c0(const Fp4Sq& q, const Fp2& z) {
+  return {fp_lc4<3, 27, -3, -2>(q.ta.c0, q.tb.c0, q.tb.c1, z.c0), fp_lc4<3, 3, 27, -2>(q.ta.c1, q.tb.c0, q.tb.c1, z.c1)};
 }
-// Granger-Scott squaring in the cyclotomic subgroup, pairings.rs:68-115 (valid with xi = 9+u)
+// 3 (s - ta - tb) + 2 z
+BN_INL Fp2 cyc_c1(const Fp4Sq& q, const Fp2& z) {
+  return {fp_lc4<3, -3, -3, 2>(q.s.c0, q.ta.c0, q.tb.c0, z.c0), fp_lc4<3, -3, -3, 2>(q.s.c1, q.ta.c1, q.tb.c1, z.c1)};
+}
 BN_FUNC Fp12 fp12_cyclotomic_sqr(const Fp12& f) {
   BN_CTX;
   Fp2 z0 = f.c0.c0, z4 = f.c0.c1, z3 = f.c0.c2, z2 = f.c1.c0, z1 = f.c1.c1, z5 = f.c1.c2;
-  Fp2 t0, t1, t2, t3, t4, t5;
-  fp4_square(t0, t1, z0, z1);
-  fp4_square(t2, t3, z2, z3);
-  fp4_square(t4, t5, z4, z5);
-  // z0 = 3 t0 - 2 z0 ; z1 = 3 t1 + 2 z1
-  Fp2 r0 = {fp_lc2<3, -2>(t0.c0, z0.c0), fp_lc2<3, -2>(t0.c1, z0.c1)};
-  Fp2 r1 = {fp_lc2<3, 2>(t1.c0, z1.c0), fp_lc2<3, 2>(t1.c1, z1.c1)};
-  // z4 = 3 t2 - 2 z4 ; z5 = 3 t3 + 2 z5
-  Fp2 r4 = {fp_lc2<3, -2>(t2.c0, z4.c0), fp_lc2<3, -2>(t2.c1, z4.c1)};
-  Fp2 r5 = {fp_lc2<3, 2>(t3.c0, z5.c0), fp_lc2<3, 2>(t3.c1, z5.c1)};
-  // z2 = 3 xi t5 + 2 z2 ; z3 = 3 t4 - 2 z3
-  Fp2 xt = fp2_mul_xi(t5);
-  Fp2 r2 = {fp_lc2<3, 2>(xt.c0, z2.c0), fp_lc2<3, 2>(xt.c1, z2.c1)};
-  Fp2 r3 = {fp_lc2<3, -2>(t4.c0, z3.c0), fp_lc2<3, -2>(t4.c1, z3.c1)};
+  Fp4Sq q01 = fp4_sq_raw(z0, z1);
+  Fp2 r0 = cyc_c0(q01, z0), r1 = cyc_c1(q01, z1);               // z0 = 3 t0 - 2 z0 ; z1 = 3 t1 + 2 z1
+  Fp4Sq q23 = fp4_sq_raw(z2, z3);
+  Fp2 r4 = cyc_c0(q23, z4), r5 = cyc_c1(q23, z5);               // z4 = 3 t2 - 2 z4 ; z5 = 3 t3 + 2 z5
+  Fp4Sq q45 = fp4_sq_raw(z4, z5);
+  Fp2 r3 = cyc_c0(q45, z3);                                     // z3 = 3 t4 - 2 z3
+  // t5 = s - ta - tb with its value brought back below ~p (a reducing pass): it is scaled by 27 next, and the three
+  // squarings of a lazily combined input can each be worth several p
+  Fp2 t5 = {fp_lc4<1, -1, -1, 0, true>(q45.s.c0, q45.ta.c0, q45.tb.c0, q45.s.c0), fp_lc4<1, -1, -1, 0, true>(q45.s.c1, q45.ta.c1, q45.tb.c1, q45.s.c1)};
+  Fp2 r2 = {fp_lc3<27, -3, 2>(t5.c0, t5.c1, z2.c0), fp_lc3<3, 27, 2>(t5.c0, t5.c1, z2.c1)};   // z2 = 3 xi t5 + 2 z2
   return {{r0, r4, r3}, {r2, r1, r5}};
 }
 BN_INL bool fp12_is_one(const Fp12& a) {

@@ -1161,8 +1161,9 @@ int oracle_sign(const uint8_t sk_be[32], const uint8_t* msg, size_t msg_len, con
 /* Exact Fp multiplication counts (mul + sqr) of the algorithmic unit "one BLS verify" of SURVEY.md 8d:
    out[0] = one-pair Miller loop with a variable Q (incl. the shared f^2), out[1] = the fixed-Q pair when its
    line coefficients are precomputed (one ell() per table entry, no point arithmetic), out[2] = final
-   exponentiation, out[3] = number of table entries. */
-void oracle_verify_core_counts(uint64_t out[4]) {
+   exponentiation, out[3] = number of table entries, out[4] = the loop's squarings of f alone (shared by all pairs of a
+   multi-pair loop: a loop whose pairs ALL come from tables costs out[4] + pairs * out[1]). */
+void oracle_verify_core_counts(uint64_t out[5]) {
   init();
   g1a p = {fp_from_u64(1), fp_from_u64(2), 0};
   g2a q = G2_GEN;
@@ -1181,6 +1182,9 @@ void oracle_verify_core_counts(uint64_t out[4]) {
   g = final_exponentiation(f12_mul(f, g));
   oracle_counters_get(&m, &s); out[2] = m + s - 54;   /* minus the f*g product above (18 Fp2 mul) */
   out[3] = (u64)lines;
+  oracle_counters_reset();
+  for (int j = ATE_NAF_LEN - 2; j >= 0; --j) g = f12_sqr(g);
+  oracle_counters_get(&m, &s); out[4] = m + s;
   (void)g;
 }
 /* Compressed codecs.  G1: 32 B = x big-endian with bit 255 = parity of y (G1Affine::to_compressed, g1.rs:283-288).

@@ -80,7 +80,7 @@ void oracle_fp_mul_refstyle(const uint8_t a[32], const uint8_t b[32], uint8_t ou
 double oracle_bench_fp_mul(int refstyle, uint64_t iters);
 
 /* instrumentation: exact Fp multiplication / squaring counts of the calling thread */
-void oracle_verify_core_counts(uint64_t out[4]);
+void oracle_verify_core_counts(uint64_t out[5]);
 void oracle_counters_reset(void);
 void oracle_counters_get(uint64_t* fp_mul, uint64_t* fp_sqr);
 

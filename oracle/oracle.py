@@ -258,8 +258,9 @@ def field_op_batch(op, a, b, n):
 
 
 def verify_core_counts():
-    """Exact Fp mul+sqr counts of the algorithmic unit: (variable-Q Miller pair, fixed-Q pair from table, final exp, table entries)."""
-    a = (ctypes.c_uint64 * 4)()
+    """Exact Fp mul+sqr counts of the algorithmic unit: (variable-Q Miller pair, fixed-Q pair from table, final exp, table
+    entries, the loop's shared squarings of f)."""
+    a = (ctypes.c_uint64 * 5)()
     lib().oracle_verify_core_counts(a)
     return tuple(int(v) for v in a)
 

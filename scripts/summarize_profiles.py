@@ -1,16 +1,17 @@
-"""Copy the round-end profile set from gpurun_out/prof_final into profiles/ and derive profiles/r01_traffic.json
-and the per-kernel VALU-busy / wait fractions quoted in DESIGN.md.  Usage: python scripts/summarize_profiles.py"""
-import collections, csv, json, os, shutil
+"""Copy the round-end profile set from gpurun_out/prof_final into profiles/ and derive profiles/<tag>_traffic.json
+and the per-kernel VALU-busy / wait fractions quoted in DESIGN.md.  Usage: python scripts/summarize_profiles.py [tag=r02]"""
+import collections, csv, json, os, shutil, sys
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_final")
 DST = os.path.join(ROOT, "profiles")
-os.makedirs(os.path.join(DST, "r01_pmc_final"), exist_ok=True)
-shutil.copy(os.path.join(SRC, "stats", "bench_kernel_stats.csv"), os.path.join(DST, "r01_final_kernel_stats.csv"))
-shutil.copy(os.path.join(SRC, "pmc_sq", "sq_counter_collection.csv"), os.path.join(DST, "r01_pmc_final", "SQ_WAVES_counter_collection.csv"))
-shutil.copy(os.path.join(SRC, "pmc_fetch", "fetch_counter_collection.csv"), os.path.join(DST, "r01_pmc_final", "FETCH_SIZE_counter_collection.csv"))
-shutil.copy(os.path.join(SRC, "pmc_write", "write_counter_collection.csv"), os.path.join(DST, "r01_pmc_final", "WRITE_SIZE_counter_collection.csv"))
+os.makedirs(os.path.join(DST, TAG + "_pmc_final"), exist_ok=True)
+shutil.copy(os.path.join(SRC, "stats", "bench_kernel_stats.csv"), os.path.join(DST, TAG + "_final_kernel_stats.csv"))
+shutil.copy(os.path.join(SRC, "pmc_sq", "sq_counter_collection.csv"), os.path.join(DST, TAG + "_pmc_final", "SQ_WAVES_counter_collection.csv"))
+shutil.copy(os.path.join(SRC, "pmc_fetch", "fetch_counter_collection.csv"), os.path.join(DST, TAG + "_pmc_final", "FETCH_SIZE_counter_collection.csv"))
+shutil.copy(os.path.join(SRC, "pmc_write", "write_counter_collection.csv"), os.path.join(DST, TAG + "_pmc_final", "WRITE_SIZE_counter_collection.csv"))
 line = [l for l in open(os.path.join(SRC, "bench.json")) if l.startswith("{")][-1]
-json.dump(json.loads(line), open(os.path.join(DST, "r01_final_bench.json"), "w"), indent=1)
+json.dump(json.loads(line), open(os.path.join(DST, TAG + "_final_bench.json"), "w"), indent=1)
 
 
 def per_kernel(path):
@@ -23,20 +24,28 @@ def per_kernel(path):
 
 f, fl = per_kernel(os.path.join(SRC, "pmc_fetch", "fetch_counter_collection.csv"))
 w, wl = per_kernel(os.path.join(SRC, "pmc_write", "write_counter_collection.csv"))
-out = {"_source": "profiles/r01_pmc_final/{FETCH,WRITE}_SIZE_counter_collection.csv (rocprofv3 --pmc, separate passes, bench.py --steps 1 "
-                  "--warmup 0, final r01 build); bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch (FETCH_SIZE/WRITE_SIZE in KiB; "
+out = {"_source": "profiles/" + TAG + "_pmc_final/{FETCH,WRITE}_SIZE_counter_collection.csv (rocprofv3 --pmc, separate passes, bench.py --steps 1 "
+                  "--warmup 0, final build of the round); bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch (FETCH_SIZE/WRITE_SIZE in KiB; "
                   "FETCH_SIZE doubled per MI355X_MICROARCH.md 'HBM'); averages over the launches of each kernel in the run", "kernels": {}}
 for k in f:
     fk, wk = f[k]["FETCH_SIZE"] / fl[k], w[k]["WRITE_SIZE"] / max(wl.get(k, 1), 1)
     out["kernels"][k] = {"fetch_kib": round(fk), "write_kib": round(wk), "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
-json.dump(out, open(os.path.join(DST, "r01_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(DST, TAG + "_traffic.json"), "w"), indent=1)
 # the bench line above was produced before this traffic file existed: carry the PMC figure of the same build into it
-bj = json.load(open(os.path.join(DST, "r01_final_bench.json")))
-t = out["kernels"]["k_miller_verify"]["hbm_bytes_per_launch"]
+bj = json.load(open(os.path.join(DST, TAG + "_final_bench.json")))
+dom = bj["roofline"]["kernel"]
+t = out["kernels"][dom]["hbm_bytes_per_launch"]
 bj["roofline"]["traffic"] = t
-bj["roofline"]["traffic_note"] = ("PMC FETCH_SIZE/WRITE_SIZE of the same kernel at the same batch size (profiles/r01_traffic.json): %.1f KB per tuple "
-                                  "against ~1.4 KB algorithmic (inputs 0.3 KB, H 72 B, f out 432 B, line table from cache)" % (t / 262144 / 1024.0))
-json.dump(bj, open(os.path.join(DST, "r01_final_bench.json"), "w"), indent=1)
+bj["roofline"]["traffic_note"] = ("PMC FETCH_SIZE/WRITE_SIZE of the same kernel at the same batch size (profiles/%s_traffic.json): %.1f KB per tuple "
+                                  "against ~0.6 KB algorithmic (sig 64 B, H 72 B, f out 432 B; line tables from cache)" % (TAG, t / 262144 / 1024.0))
+for extra in ("bench_exact.json", "configs.json", "valu_peak.json"):
+    src = os.path.join(SRC, extra)
+    if os.path.exists(src):
+        txt = open(src).read()
+        if extra == "bench_exact.json":
+            txt = json.dumps(json.loads([l for l in txt.splitlines() if l.startswith("{")][-1]), indent=1)
+        open(os.path.join(DST, TAG + "_" + extra.replace("bench_exact", "exact_path_bench")), "w").write(txt)
+json.dump(bj, open(os.path.join(DST, TAG + "_final_bench.json"), "w"), indent=1)
 s, sl = per_kernel(os.path.join(SRC, "pmc_sq", "sq_counter_collection.csv"))
 for k, v in sorted(s.items(), key=lambda kv: -kv[1]["SQ_WAVE_CYCLES"]):
     wc = v["SQ_WAVE_CYCLES"] or 1
