@@ -41,7 +41,7 @@ struct blsbn254_ctx {
   DevBuf rlc_a2, rlc_a, rlc_b, rlc_elig, rlc_f2, rlc_bytes, rlc_neg, rlc_ok, rlc_idx, rlc_cpk, rlc_csig, rlc_ch, rlc_csub, rlc_cbm;   // RLC batch verification
   DevBuf status_all;     // per-element decode status of a chunked call, all chunks
   // prepared-key verify path (k_keyprep.hip, k_miller_prep.hip)
-  DevBuf kd_slots, kd_rep, kd_kid, kd_keys, kd_hist, kd_cursor, kd_perm, kd_cnt, prep_table, prep_ok, prep_isone, prep_valid;
+  DevBuf kd_slots, kd_rep, kd_kid, kd_keys, kd_hist, kd_cursor, kd_perm, kd_cnt, prep_table, prep_raw, prep_ok, prep_isone, prep_valid;
   hipStream_t stream2 = nullptr;     // the per-key preparation runs beside hash-to-G1
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   uint32_t kd_seed = 0;              // per-context random seed of the key hash table
@@ -149,7 +149,7 @@ void blsbn254_ctx_destroy(blsbn254_ctx* c) {
   { DevBuf* tb[] = {&c->th_x, &c->th_num, &c->th_den, &c->th_glv, &c->th_part, &c->th_part2, &c->q_ws}; for (DevBuf* b : tb) b->release(); }
   { DevBuf* rb[] = {&c->rlc_a2, &c->rlc_a, &c->rlc_b, &c->rlc_elig, &c->rlc_f2, &c->rlc_bytes, &c->rlc_neg, &c->rlc_ok, &c->rlc_idx, &c->rlc_cpk, &c->rlc_csig, &c->rlc_ch, &c->rlc_csub, &c->rlc_cbm};
     for (DevBuf* b : rb) b->release(); }
-  { DevBuf* kb[] = {&c->kd_slots, &c->kd_rep, &c->kd_kid, &c->kd_keys, &c->kd_hist, &c->kd_cursor, &c->kd_perm, &c->kd_cnt, &c->prep_table, &c->prep_ok,
+  { DevBuf* kb[] = {&c->kd_slots, &c->kd_rep, &c->kd_kid, &c->kd_keys, &c->kd_hist, &c->kd_cursor, &c->kd_perm, &c->kd_cnt, &c->prep_table, &c->prep_raw, &c->prep_ok,
                     &c->prep_isone, &c->prep_valid};
     for (DevBuf* b : kb) b->release(); }
   (void)hipStreamSynchronize(c->stream2);
@@ -487,14 +487,17 @@ int blsbn254_g2_check_batch(blsbn254_ctx* c, const uint8_t* g2, size_t n, uint8_
 // larger than ctx->chunk (4 Mi) tuples are processed chunk by chunk so that any n fits the 288 GB of HBM.
 // ---- prepared-key path.  Limits: key ids and table offsets are 32-bit (88 x 54 x 4 B per key): at most PREP_MAX_KEYS keys.
 static const size_t PREP_MAX_KEYS = (size_t)1 << 16;
-static const size_t PREP_KEY_LIMBS = (size_t)BN_NEG_G2_LINES * 54;
+static const size_t PREP_RAW_LIMBS = (size_t)BN_NEG_G2_LINES * 54;       // a key's 88 line triples
+static const size_t PREP_KEY_LIMBS = (size_t)BN_NEG_G2_LINES * 162;      // a key's 88 expanded line pairs (key line x -G2gen line)
 
 // G2Prepared::from for u keys on the second stream (after ev_fork), ev_join recorded behind it.
 // keys == nullptr: key k = pks[128 k]; else key k = the public key of tuple keys[k].
 static int prepare_keys_async(blsbn254_ctx* c, const uint8_t* d_pks, const uint32_t* d_keys, size_t u, int32_t* table, uint8_t* key_ok) {
+  HIPCHK(c, c->prep_raw.reserve(u * PREP_RAW_LIMBS * 4));
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-  LAUNCH2(c, "g2_prepare", k_g2_prepare, u, d_pks, d_keys, (uint32_t)u, table, key_ok);
+  LAUNCH2(c, "g2_prepare", k_g2_prepare, u, d_pks, d_keys, (uint32_t)u, (int32_t*)c->prep_raw.p, key_ok);
+  LAUNCH2(c, "g2_expand", k_g2_expand, u * (size_t)BN_NEG_G2_LINES, (const int32_t*)c->prep_raw.p, (uint32_t)u, table);
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
   return 0;
 }
@@ -608,7 +611,9 @@ int blsbn254_g2_prepare_batch(blsbn254_ctx* c, const uint8_t* pks, size_t u, bls
     hipError_t e1 = p->table.reserve(u * PREP_KEY_LIMBS * 4), e2 = p->ok.reserve(u), e3 = c->in_a.reserve(128 * u);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { p->table.release(); p->ok.release(); delete p; return BLSBN254_E_NOMEM; }
     HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * u, hipMemcpyHostToDevice, c->stream));
-    LAUNCH(c, "g2_prepare", k_g2_prepare, u, (const uint8_t*)c->in_a.p, (const uint32_t*)nullptr, (uint32_t)u, (int32_t*)p->table.p, (uint8_t*)p->ok.p);
+    if (c->prep_raw.reserve(u * PREP_RAW_LIMBS * 4) != hipSuccess) { p->table.release(); p->ok.release(); delete p; return BLSBN254_E_NOMEM; }
+    LAUNCH(c, "g2_prepare", k_g2_prepare, u, (const uint8_t*)c->in_a.p, (const uint32_t*)nullptr, (uint32_t)u, (int32_t*)c->prep_raw.p, (uint8_t*)p->ok.p);
+    LAUNCH(c, "g2_expand", k_g2_expand, u * (size_t)BN_NEG_G2_LINES, (const int32_t*)c->prep_raw.p, (uint32_t)u, (int32_t*)p->table.p);
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   *out = p;

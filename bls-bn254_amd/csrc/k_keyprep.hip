@@ -6,6 +6,8 @@
 //     optimal ate loop written as a table (g2_prepare_lines, pairing.h);
 //   * the small kernels that carry validity back from key-sorted order to the caller's order.
 // Own translation unit, tower / curve functions force-inlined.
+#define BN_WANT_LINE_TABLE
+#define BN_LINE_TABLE_QUAL static __device__ const
 #include "lane_ops.h"
 #include "kernels.h"
 using namespace bn;
@@ -93,6 +95,15 @@ BN_KERNEL k_g2_prepare(const uint8_t* pks, const uint32_t* keys, uint32_t u, int
   q.x = fp2_select(ok, q.x, fp2_const(bnc::G2_GEN_X)); q.y = fp2_select(ok, q.y, fp2_const(bnc::G2_GEN_Y)); q.inf = false;
   g2_prepare_lines(q, Ws{table, 1, k * (uint32_t)(BN_NEG_G2_LINES * 54 * 4), true});
   key_ok[k] = ok ? 1 : 0;
+}
+// The pair tables: lane (key k, step t) multiplies the key's line t with the fixed -G2gen line t (pairing.h line_pair_expand):
+// raw (u x 88 x 54 limbs) -> expanded (u x 88 x 162 limbs).  u x 88 lanes: the part of the preparation that is not sequential.
+BN_KERNEL k_g2_expand(const int32_t* raw, uint32_t u, int32_t* expanded) {
+  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= u * (uint32_t)BN_NEG_G2_LINES) return;
+  const uint32_t t = e % (uint32_t)BN_NEG_G2_LINES;
+  const Line b = line_load_limbs(Ws{const_cast<int32_t*>(raw), 1, e * (uint32_t)(54 * 4), true});
+  line_pair_expand(line_from_table(BN_NEG_G2_LINE_TABLE[t]), b, Ws{expanded, 1, e * (uint32_t)(162 * 4), true});
 }
 // valid (caller's order, one byte per tuple) from the key-sorted results: is_one[s] & flags[s] of sorted position s = perm^-1
 __global__ void k_prep_unsort(const uint8_t* is_one, const uint8_t* flags, const uint32_t* perm, uint32_t n, uint8_t* valid) {

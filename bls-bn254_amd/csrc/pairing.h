@@ -516,32 +516,65 @@ BN_FUNC void g2_prepare_lines(const G2A& q, const Ws& out) {
   line_store_limbs(ws_at(out, 54 * (size_t)ti++), addition_step(T, q1x, q1y));
   line_store_limbs(ws_at(out, 54 * (size_t)ti++), addition_step(T, q2x, q2y));
 }
-// f = ML(sig, -G2gen) * ML(H, pk) with BOTH pairs' lines read from tables: `table` the generated -G2gen lines (wave-uniform
-// address), `ktab` this lane's key (per-lane base; waves are key-sorted, so the 64 lanes mostly read one address).
-// inv (LDS): sig.x, sig.y, H.x, H.y, 9 limbs each.  The key line of a step is fetched before the squaring that hides it.
-BN_FUNC Fp12 miller_loop_prepared(const Ws& inv, const int32_t (*table)[54], const Ws& ktab_in) {
+// Both pairs from tables, one step further: the first pair's table (-G2gen) is the same for every tuple, so the PRODUCT of
+// the two lines of a step can be prepared per key as well.  With la = a0 ys + a3 xs w + a4 w^3 (a: -G2gen line, (xs, ys) the
+// signature) and lb = b0 yh + b3 xh w + b4 w^3 (b: the key's line, (xh, yh) = H(msg)):
+//   la lb = (a0b0 ys yh + xi a4b4) + a3b3 xs xh v + (a3b4 xs + a4b3 xh) v^2 + [(a0b3 ys xh + a3b0 xs yh) + (a0b4 ys + a4b0 yh) v] w
+// The nine Fp2 products a_i b_j depend on the key only (k_g2_expand, 162 limbs per line: T0 = a0b0, T1 = xi a4b4, T2 = a3b3,
+// T3 = a3b4, T4 = a4b3, T5 = a0b3, T6 = a3b0, T7 = a0b4, T8 = a4b0); per tuple four products of coordinates are formed once.
+// A step then spends 2 scalings + 3 double products (2106 MADs) on the line pair instead of 4 scalings + 6 Fp2 products
+// (4212), and the 17-product sparse multiplication of f is unchanged.  Same field values, hence the same bitmap.
+BN_FUNC void line_pair_expand(const Line& a, const Line& b, const Ws& out) {
+  BN_CTX;
+  fp2_store_limbs(out, fp2_mul(a.c0, b.c0));
+  fp2_store_limbs(ws_at(out, 18), fp2_mul_xi(fp2_mul(a.c2, b.c2)));
+  fp2_store_limbs(ws_at(out, 36), fp2_mul(a.c1, b.c1));
+  fp2_store_limbs(ws_at(out, 54), fp2_mul(a.c1, b.c2));
+  fp2_store_limbs(ws_at(out, 72), fp2_mul(a.c2, b.c1));
+  fp2_store_limbs(ws_at(out, 90), fp2_mul(a.c0, b.c1));
+  fp2_store_limbs(ws_at(out, 108), fp2_mul(a.c1, b.c0));
+  fp2_store_limbs(ws_at(out, 126), fp2_mul(a.c0, b.c2));
+  fp2_store_limbs(ws_at(out, 144), fp2_mul(a.c2, b.c0));
+}
+BN_INL Fp2 fp2_dot_fp(const Fp2& t, const Fp& s, const Fp2& u, const Fp& r) {      // t s + u r, one reduction per component
+  return {fp_dot2(t.c0, s, u.c0, r), fp_dot2(t.c1, s, u.c1, r)};
+}
+// f * (la lb) from the expanded pair `e` (this step's 162 limbs) and the tuple's coordinates in `cw` (LDS, 9 limbs each:
+// xs, ys, xh, yh, ys yh, xs xh, ys xh, xs yh)
+BN_FUNC Fp12 ell_pair_expanded(const Fp12& f, const Ws& e, const Ws& cw) {
+  BN_CTX;
+  Fp xs = fp_load_mem(cw), ys = fp_load_mem(ws_at(cw, 9)), xh = fp_load_mem(ws_at(cw, 18)), yh = fp_load_mem(ws_at(cw, 27));
+  Fp ysyh = fp_load_mem(ws_at(cw, 36)), xsxh = fp_load_mem(ws_at(cw, 45)), ysxh = fp_load_mem(ws_at(cw, 54)), xsyh = fp_load_mem(ws_at(cw, 63));
+  Fp6 l0 = {fp2_norm(fp2_add(fp2_mul_fp(fp2_load_limbs(e), ysyh), fp2_load_limbs(ws_at(e, 18)))),
+            fp2_mul_fp(fp2_load_limbs(ws_at(e, 36)), xsxh),
+            fp2_dot_fp(fp2_load_limbs(ws_at(e, 54)), xs, fp2_load_limbs(ws_at(e, 72)), xh)};
+  Fp2 l10 = fp2_dot_fp(fp2_load_limbs(ws_at(e, 90)), ysxh, fp2_load_limbs(ws_at(e, 108)), xsyh);
+  Fp2 l11 = fp2_dot_fp(fp2_load_limbs(ws_at(e, 126)), ys, fp2_load_limbs(ws_at(e, 144)), yh);
+  Fp6 v0 = fp6_mul(f.c0, l0);
+  Fp6 v1 = fp6_mul_by_01(f.c1, l10, l11);
+  Fp6 dl = {fp2_norm(fp2_sub(l10, l0.c0)), fp2_norm(fp2_sub(l11, l0.c1)), fp2_norm(fp2_neg(l0.c2))};       // l1 - l0
+  Fp6 w = fp6_mul(fp6_norm(fp6_sub(f.c0, f.c1)), dl);
+  return {fp6_add_mul_v(v0, v1), fp6_norm(fp6_add(fp6_add(w, v0), v1))};
+}
+// inv (LDS, 72 limbs): xs, ys, xh, yh and their four products; ktab: this lane's key, 88 x 162 limbs
+BN_FUNC Fp12 miller_loop_prepared(const Ws& inv, const Ws& ktab_in) {
   Fp12 f = fp12_one();
   Ws p = inv, kt = ktab_in;
   int ti = 0;
   for (int j = bnc::ATE_NAF_LEN - 2; j >= 0; --j) {
-    BN_OPAQUE(kt);
-    Line lk = line_load_limbs(ws_at(kt, 54 * (size_t)ti));
-    BN_SCHED_BARRIER;
     f = fp12_sqr(f);
-    BN_OPAQUE(p);
-    f = ell2(f, line_from_table(table[ti]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)), lk, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
+    BN_OPAQUE(kt); BN_OPAQUE(p);
+    f = ell_pair_expanded(f, ws_at(kt, 162 * (size_t)ti), p);
     ++ti;
     if (ate_naf_digit(j) != 0) {
       BN_OPAQUE(kt); BN_OPAQUE(p);
-      lk = line_load_limbs(ws_at(kt, 54 * (size_t)ti));
-      f = ell2(f, line_from_table(table[ti]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)), lk, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
+      f = ell_pair_expanded(f, ws_at(kt, 162 * (size_t)ti), p);
       ++ti;
     }
   }
   for (int e = 0; e < 2; ++e) {
     BN_OPAQUE(kt); BN_OPAQUE(p);
-    Line lk = line_load_limbs(ws_at(kt, 54 * (size_t)ti));
-    f = ell2(f, line_from_table(table[ti]), fp_load_mem(p), fp_load_mem(ws_at(p, 9)), lk, fp_load_mem(ws_at(p, 18)), fp_load_mem(ws_at(p, 27)));
+    f = ell_pair_expanded(f, ws_at(kt, 162 * (size_t)ti), p);
     ++ti;
   }
   return f;
