@@ -570,7 +570,7 @@ static int verify_chunk_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t
       rc = prepare_keys_async(c, d_pks, (const uint32_t*)c->kd_keys.p, u, (int32_t*)c->prep_table.p, (uint8_t*)c->prep_ok.p);
       if (rc) return rc;
       HIPCHK(c, hipMemsetAsync(c->kd_hist.p, 0, 4 * u, c->stream));
-      LAUNCH(c, "kd_propagate", k_kd_propagate, n, (const uint32_t*)c->kd_rep.p, (uint32_t)n, (uint32_t*)c->kd_kid.p, (uint32_t*)c->kd_hist.p);
+      LAUNCH(c, "kd_propagate", k_kd_propagate, n, (const uint32_t*)c->kd_rep.p, (uint32_t)n, (uint32_t)u, (uint32_t*)c->kd_kid.p, (uint32_t*)c->kd_hist.p);
       ++c->stat_prepared_chunks;
       return verify_prepared_dev(c, (const int32_t*)c->prep_table.p, (const uint8_t*)c->prep_ok.p, u, (const uint32_t*)c->kd_kid.p, true,
                                  d_msgs, d_off, d_sigs, n, dl, d_bitmap, true);
@@ -818,18 +818,43 @@ static int aggregate_partial_impl(blsbn254_ctx* c, const uint8_t* pks, const uin
   int* d_ok = (int*)c->misc.p;                               // [0] all keys valid, [1] (byte) signature valid
   static const int ones[2] = {1, 1};
   HIPCHK(c, hipMemcpyAsync(d_ok, ones, 8, hipMemcpyHostToDevice, c->stream));
-  // hash and key checks over the caller's n pairs; their H points land in slots 0..n-1 of a stride-np workspace
-  if (n) {
-    LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, np, (uint8_t*)nullptr, 0);
-    LAUNCH(c, "g2_check", k_g2_check, n, (const uint8_t*)c->in_a.p, n, (uint8_t*)c->sub_ok.p, (uint8_t*)nullptr);
-  }
   if (extra_sig) {
     HIPCHK(c, hipMemcpyAsync(c->in_b.p, extra_sig, 64, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync((uint8_t*)c->in_a.p + 128 * n, NEG_G2_BYTES, 128, hipMemcpyHostToDevice, c->stream));
-    LAUNCH(c, "g1_to_ws", k_g1_to_ws, 1, (const uint8_t*)c->in_b.p, (int32_t*)c->h_ws.p, n, np, (uint8_t*)(d_ok + 1));
   }
-  LAUNCH(c, "miller_hpk2", k_miller_hpk2, n_lanes, (const int32_t*)c->h_ws.p, (const uint8_t*)c->in_a.p, np, (int32_t*)c->q_ws.p, f, n_lanes, (uint8_t*)c->flags.p);
-  if (n) { LAUNCH(c, "and_reduce", k_and_reduce, n, (const uint8_t*)c->flags.p, (const uint8_t*)c->sub_ok.p, n, d_ok); }
+  // few distinct keys among the np pairs (the pair (sig, -G2gen) included)?  then prepare each once, beside the hashing
+  bool prepared = false;
+  if (c->auto_prepare && np >= 1024) {
+    size_t u = 0;
+    rc = dedup_keys(c, (const uint8_t*)c->in_a.p, np, &u);
+    if (rc) return rc;
+    if (u * 2 <= np && u <= PREP_MAX_KEYS) {
+      HIPCHK(c, c->prep_table.reserve(64)); HIPCHK(c, c->prep_ok.reserve(u)); HIPCHK(c, c->prep_raw.reserve(u * PREP_RAW_LIMBS * 4));
+      HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+      HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+      LAUNCH2(c, "g2_prepare", k_g2_prepare, u, (const uint8_t*)c->in_a.p, (const uint32_t*)c->kd_keys.p, (uint32_t)u, (int32_t*)c->prep_raw.p, (uint8_t*)c->prep_ok.p);
+      HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+      LAUNCH(c, "kd_propagate", k_kd_propagate, np, (const uint32_t*)c->kd_rep.p, (uint32_t)np, (uint32_t)u, (uint32_t*)c->kd_kid.p, (uint32_t*)nullptr);   // no sorting here: no histogram
+      prepared = true;
+    }
+  }
+  // hash (and, on the exact path, key checks) over the caller's n pairs; their H points land in slots 0..n-1 of a stride-np workspace
+  if (n) {
+    LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, np, (uint8_t*)nullptr, 0);
+    if (!prepared) { LAUNCH(c, "g2_check", k_g2_check, n, (const uint8_t*)c->in_a.p, n, (uint8_t*)c->sub_ok.p, (uint8_t*)nullptr); }
+  }
+  if (extra_sig) { LAUNCH(c, "g1_to_ws", k_g1_to_ws, 1, (const uint8_t*)c->in_b.p, (int32_t*)c->h_ws.p, n, np, (uint8_t*)(d_ok + 1)); }
+  if (prepared) {
+    // few distinct keys: every key (and -G2gen, when the signature's pair is carried) was validated and turned into its line
+    // table once, beside hash-to-G1; the pairs read their lines from those tables
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    LAUNCH(c, "miller_hpk2p", k_miller_hpk2p, n_lanes, (const int32_t*)c->h_ws.p, np, (const uint32_t*)c->kd_kid.p, (const int32_t*)c->prep_raw.p,
+           (const uint8_t*)c->prep_ok.p, np, f, n_lanes, (uint8_t*)c->flags.p);
+    if (n) { LAUNCH(c, "and_reduce", k_and_reduce, n, (const uint8_t*)c->flags.p, (const uint8_t*)c->flags.p, n, d_ok); }
+  } else {
+    LAUNCH(c, "miller_hpk2", k_miller_hpk2, n_lanes, (const int32_t*)c->h_ws.p, (const uint8_t*)c->in_a.p, np, (int32_t*)c->q_ws.p, f, n_lanes, (uint8_t*)c->flags.p);
+    if (n) { LAUNCH(c, "and_reduce", k_and_reduce, n, (const uint8_t*)c->flags.p, (const uint8_t*)c->sub_ok.p, n, d_ok); }
+  }
   int32_t* res; size_t rs;
   rc = fp12_tree(c, f, n_lanes, n_lanes, &res, &rs);
   if (rc) return rc;

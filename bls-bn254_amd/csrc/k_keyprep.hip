@@ -34,7 +34,10 @@ __global__ void k_kd_insert(const uint8_t* pks, uint32_t n, uint32_t* slots, uin
   const uint8_t* mine = pks + 128 * (size_t)i;
   uint32_t s = key_hash(mine, seed) & mask;
   for (;;) {                                             // terminates: the table has at least 2n slots
-    uint32_t old = atomicCAS(&slots[s], 0xffffffffu, i);
+    // read first: with few distinct keys almost every probe finds its slot taken, and a million CAS operations on a handful
+    // of addresses serialise in the L2 atomic units (1.5 ms for 2^20 tuples over 9 keys); a slot never changes once taken
+    uint32_t old = __atomic_load_n(&slots[s], __ATOMIC_RELAXED);
+    if (old == 0xffffffffu) old = atomicCAS(&slots[s], 0xffffffffu, i);
     if (old == 0xffffffffu) { rep[i] = i; return; }
     if (key_equal(mine, pks + 128 * (size_t)old)) { rep[i] = old; return; }
     s = (s + 1) & mask;
@@ -47,12 +50,27 @@ __global__ void k_kd_assign(const uint32_t* rep, uint32_t n, uint32_t* kid, uint
   uint32_t id = atomicAdd(counter, 1u);
   kid[i] = id; keys[id] = i;
 }
-__global__ void k_kd_propagate(const uint32_t* rep, uint32_t n, uint32_t* kid, uint32_t* hist) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t id = kid[rep[i]];
-  kid[i] = id;
-  atomicAdd(&hist[id], 1u);
+// kid of every tuple; hist (optional, for the key-sorted order): tuples per key.  The counts of a workgroup are first
+// gathered in LDS when the key ids fit (u <= 8192), so that a batch over a handful of keys does not send every tuple's
+// increment to the same few global addresses.
+__global__ void __launch_bounds__(256) k_kd_propagate(const uint32_t* rep, uint32_t n, uint32_t u, uint32_t* kid, uint32_t* hist) {
+  __shared__ uint32_t lh[8192];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool use_lds = hist != nullptr && u <= 8192u;
+  if (use_lds) {
+    for (uint32_t k = threadIdx.x; k < u; k += blockDim.x) lh[k] = 0;
+    __syncthreads();
+  }
+  if (i < n) {
+    const uint32_t id = kid[rep[i]];
+    kid[i] = id;
+    if (use_lds) atomicAdd(&lh[id], 1u);
+    else if (hist) atomicAdd(&hist[id], 1u);
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < u; k += blockDim.x) { uint32_t v = lh[k]; if (v) atomicAdd(&hist[k], v); }
+  }
 }
 // histogram over explicit key indices (the G2Prepared API: the caller names the key of every tuple); bad = an index >= u
 __global__ void k_kd_hist(const uint32_t* kid, uint32_t n, uint32_t u, uint32_t* hist, int* bad) {

@@ -30,6 +30,8 @@ BN_KERNEL k_g2_check(const uint8_t* g2, size_t n, uint8_t* ok_bytes, uint8_t* bi
 BN_KERNEL k_miller_1(const uint8_t* g1, const uint8_t* g2, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status);
 BN_KERNEL k_miller_hpk(const int32_t* h_ws, const uint8_t* pks, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* flags);
 BN_KERNEL k_miller_hpk2(const int32_t* h_ws, const uint8_t* pks, size_t n, int32_t* q_ws, int32_t* f_ws, size_t f_stride, uint8_t* flags);
+BN_KERNEL k_miller_hpk2p(const int32_t* h_ws, size_t h_stride, const uint32_t* kid, const int32_t* table, const uint8_t* key_ok, size_t n,
+                         int32_t* f_ws, size_t f_stride, uint8_t* flags);
 BN_KERNEL k_g1_to_ws(const uint8_t* g1, int32_t* h_ws, size_t slot, size_t stride, uint8_t* ok);
 BN_KERNEL k_miller_verify(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n, int32_t* f_ws, uint8_t* flags);
 BN_KERNEL k_fe_easy(const int32_t* in, int32_t* out, size_t n, size_t stride);
@@ -65,7 +67,7 @@ BN_KERNEL k_gt_pow(const uint8_t* gt, const uint8_t* scalars, size_t n, uint8_t*
 BN_KERNEL k_fr_decode(const uint8_t* ids, size_t t, int32_t* x_ws, uint8_t* status);
 __global__ void k_kd_insert(const uint8_t* pks, uint32_t n, uint32_t* slots, uint32_t mask, uint32_t seed, uint32_t* rep);
 __global__ void k_kd_assign(const uint32_t* rep, uint32_t n, uint32_t* kid, uint32_t* counter, uint32_t* keys);
-__global__ void k_kd_propagate(const uint32_t* rep, uint32_t n, uint32_t* kid, uint32_t* hist);
+__global__ void __launch_bounds__(256) k_kd_propagate(const uint32_t* rep, uint32_t n, uint32_t u, uint32_t* kid, uint32_t* hist);
 __global__ void k_kd_hist(const uint32_t* kid, uint32_t n, uint32_t u, uint32_t* hist, int* bad);
 __global__ void __launch_bounds__(1024) k_scan_excl(const uint32_t* hist, uint32_t u, uint32_t* cursor);
 __global__ void k_kd_scatter(const uint32_t* kid, uint32_t n, uint32_t u, uint32_t* cursor, uint32_t* perm);

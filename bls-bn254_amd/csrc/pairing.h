@@ -580,4 +580,29 @@ BN_FUNC Fp12 miller_loop_prepared(const Ws& inv, const Ws& ktab_in) {
   return f;
 }
 
+// Two pairs per lane, BOTH with prepared keys (aggregate verify over a batch that repeats few public keys): f = ML(Ha, Qa) *
+// ML(Hb, Qb) with the line triples of Qa and Qb read from their keys' raw tables (88 x 54 limbs each, k_g2_prepare) -- one
+// squaring of f and one two-line product per loop digit, no point arithmetic.  hh (LDS): Ha.x, Ha.y, Hb.x, Hb.y.
+// A dead half (padding of an odd count) contributes the constant line 1 evaluated at y = 1.
+BN_FUNC Fp12 ell2_from_tables(const Fp12& f, const Ws& ta_in, const Ws& tb_in, int ti, const Ws& hh_in, bool live_a, bool live_b) {
+  Ws hh = hh_in, ta = ta_in, tb = tb_in;
+  BN_OPAQUE(ta); BN_OPAQUE(tb); BN_OPAQUE(hh);
+  Line la = line_mask(live_a, line_load_limbs(ws_at(ta, 54 * (size_t)ti)));
+  Line lb = line_mask(live_b, line_load_limbs(ws_at(tb, 54 * (size_t)ti)));
+  Fp hax = fp_load_mem(hh), hay = fp_load_mem(ws_at(hh, 9)), hbx = fp_load_mem(ws_at(hh, 18)), hby = fp_load_mem(ws_at(hh, 27));
+  return ell2(f, la, hax, hay, lb, hbx, hby);
+}
+BN_FUNC Fp12 miller_loop_2prepared(const Ws& hh, const Ws& ta, const Ws& tb, bool live_a, bool live_b) {
+  Fp12 f = fp12_one();
+  int ti = 0;
+  for (int j = bnc::ATE_NAF_LEN - 2; j >= 0; --j) {
+    f = fp12_sqr(f);
+    f = ell2_from_tables(f, ta, tb, ti++, hh, live_a, live_b);
+    if (ate_naf_digit(j) != 0) f = ell2_from_tables(f, ta, tb, ti++, hh, live_a, live_b);
+  }
+  f = ell2_from_tables(f, ta, tb, ti++, hh, live_a, live_b);
+  f = ell2_from_tables(f, ta, tb, ti++, hh, live_a, live_b);
+  return f;
+}
+
 }  // namespace bn

@@ -689,3 +689,33 @@ def test_explicit_g2prepared_api(eng, oracle, M):
         eng.verify_batch_prepared(prep, [0, 8], msgs[:2], b"".join(sigs[:2]), dst)          # key index out of range
     assert e.value.code == -1
     prep.close()
+
+
+@pytest.mark.parametrize("n,pool", [(1023, 3), (1024, 3), (1501, 40)])
+def test_aggregate_with_repeated_keys_prepared_path(eng, oracle, M, n, pool):
+    """Aggregate verify over a batch that repeats few public keys: from 1024 pairs on the keys are de-duplicated and prepared
+    once and the two-pairs-per-lane loop reads both keys' lines from tables (k_miller_hpk2p).  The shard's partial product
+    equals the oracle's multi_miller_loop bit for bit on either path, with and without the signature's pair."""
+    dst = M.DEFAULT_DST
+    sks = [synth.sk_of(k) for k in range(pool)]
+    pkp = [oracle.sk_to_pk(s) for s in sks]
+    msgs = [synth.msg_of(7000 + i) for i in range(n)]
+    pks = b"".join(pkp[i % pool] for i in range(n))
+    h = eng.hash_to_g1_batch(msgs, dst)
+    # aggregate signature = sum_k sk_k * (sum of the H(msg_i) signed by key k)
+    agg = IDENT1
+    for k in range(pool):
+        acc = IDENT1
+        for i in range(k, n, pool):
+            acc = oracle.g1_add(acc, h[64 * i:64 * i + 64])
+        agg = oracle.g1_add(agg, oracle.g1_mul(acc, sks[k]))
+    want = oracle.multi_miller_loop(h, pks, n)
+    for auto in (True, False):
+        eng.set_auto_prepare(auto)
+        part, ok = eng.aggregate_partial(pks, msgs, dst)
+        assert ok and part == want
+        assert eng.aggregate_verify(pks, msgs, agg, dst) is True
+        bad = list(msgs); bad[n // 2] = b"tampered"
+        assert eng.aggregate_verify(pks, bad, agg, dst) is False
+        assert eng.aggregate_verify(pks[:128 * (n - 1)] + synth.NON_SUBGROUP_PK, msgs, agg, dst) is False
+    eng.set_auto_prepare(True)
