@@ -15,8 +15,12 @@ BN_KERNEL k_miller_hpk(const int32_t* h_ws, const uint8_t* pks, size_t n, int32_
   bool pk_ok = okp & !pk.inf & g2_on_curve(pk);
   pk.x = fp2_select(pk_ok, pk.x, fp2_const(bnc::G2_GEN_X)); pk.y = fp2_select(pk_ok, pk.y, fp2_const(bnc::G2_GEN_Y));
   pk.inf = false;
+  __shared__ int32_t lds[108 * 256];             // invariants (54 limbs) + the parked running point (54): own column per lane, no barrier
+  const Ws ws = {lds, 256, threadIdx.x * 4u, false};
   const Ws hw = {const_cast<int32_t*>(h_ws), n, i * 4u, true};
-  G1A h; h.x = fp_load_mem(hw); h.y = fp_load_mem(ws_at(hw, 9)); h.inf = false;
-  fp12_store_limbs(Ws{f_ws, f_stride, i * 4u, true}, miller_loop_1(h, pk));
+  fp_store_mem(ws, fp_load_mem(hw)); fp_store_mem(ws_at(ws, 9), fp_load_mem(ws_at(hw, 9)));
+  fp2_store_mem(ws_at(ws, 18), fp2_norm(pk.x)); fp2_store_mem(ws_at(ws, 36), fp2_norm(pk.y));
+  BN_MEM_FENCE;
+  fp12_store_limbs(Ws{f_ws, f_stride, i * 4u, true}, miller_loop_1_ws(ws, ws_at(ws, 54)));
   flags[i] = pk_ok ? 1 : 0;
 }

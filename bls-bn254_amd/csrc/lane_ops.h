@@ -56,7 +56,8 @@ BN_FUNC bool lane_g2_check(const uint8_t* g2) {
 }
 
 // ---- Miller loops.  status bit0: g1 decoded, bit1: g2 decoded, bit2: either point is the identity.
-BN_FUNC Fp12 lane_miller_1(const uint8_t* g1, const uint8_t* g2, uint8_t& status) {
+// ws (device kernels, -DBN_MILLER1_WS): this lane's LDS column of 108 limbs -- invariants (54) and the parked running point (54)
+BN_FUNC Fp12 lane_miller_1(const uint8_t* g1, const uint8_t* g2, uint8_t& status, const Ws* ws = nullptr) {
   bool ok1, ok2;
   G1A p = g1_decode(g1, ok1);
   G2A q = g2_decode(g2, ok2);
@@ -69,7 +70,14 @@ BN_FUNC Fp12 lane_miller_1(const uint8_t* g1, const uint8_t* g2, uint8_t& status
   G2A gq; gq.x = fp2_const(bnc::G2_GEN_X); gq.y = fp2_const(bnc::G2_GEN_Y); gq.inf = false;
   p.x = fp_select(bad, gp.x, p.x); p.y = fp_select(bad, gp.y, p.y);
   q.x = fp2_select(bad, gq.x, q.x); q.y = fp2_select(bad, gq.y, q.y);
+#ifdef BN_MILLER1_WS
+  fp_store_mem(*ws, fp_norm(p.x)); fp_store_mem(ws_at(*ws, 9), fp_norm(p.y));
+  fp2_store_mem(ws_at(*ws, 18), fp2_norm(q.x)); fp2_store_mem(ws_at(*ws, 36), fp2_norm(q.y));
+  BN_MEM_FENCE;
+  Fp12 f = miller_loop_1_ws(*ws, ws_at(*ws, 54));
+#else
   Fp12 f = miller_loop_1(p, q);
+#endif
   Fp12 one = fp12_one();
   f.c0 = {fp2_select(bad, one.c0.c0, f.c0.c0), fp2_select(bad, one.c0.c1, f.c0.c1), fp2_select(bad, one.c0.c2, f.c0.c2)};
   f.c1 = {fp2_select(bad, one.c1.c0, f.c1.c0), fp2_select(bad, one.c1.c1, f.c1.c1), fp2_select(bad, one.c1.c2, f.c1.c2)};

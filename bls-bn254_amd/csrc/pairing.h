@@ -249,6 +249,55 @@ BN_FUNC Fp12 miller_loop_verify_ws2(const Ws& inv, const Ws& park_in, const int3
   return f;
 }
 
+// The one-pair loop with its invariants and the running point parked (the scheme of the loops above): `inv` (LDS, 54 limbs)
+// holds P.x, P.y (9 each) and Q.x, Q.y (18 each), `park` (LDS, 54 limbs) holds T except while its line step runs.  Same
+// values as miller_loop_1.
+BN_FUNC Fp12 miller_loop_1_ws(const Ws& inv_in, const Ws& park_in) {
+  Fp12 f = fp12_one();
+  Ws p = inv_in, park = park_in;
+  fp2_store_mem(park, fp2_load_mem(ws_at(p, 18))); fp2_store_mem(ws_at(park, 18), fp2_load_mem(ws_at(p, 36))); fp2_store_mem(ws_at(park, 36), fp2_one());
+  BN_MEM_FENCE;
+  for (int j = bnc::ATE_NAF_LEN - 2; j >= 0; --j) {
+    f = fp12_sqr(f);
+    BN_OPAQUE(p); BN_OPAQUE(park);
+    Fp px = fp_load_mem(p), py = fp_load_mem(ws_at(p, 9));
+    G2J T = g2j_load(park);
+    BN_SCHED_BARRIER;
+    Line l = doubling_step(T);
+    g2j_store(park, T);
+    BN_MEM_FENCE;
+    f = ell(f, l, px, py);
+    int d = ate_naf_digit(j);
+    if (d != 0) {
+      BN_OPAQUE(p); BN_OPAQUE(park);
+      Fp2 qy = fp2_load_mem(ws_at(p, 36));
+      Fp2 nqy = fp2_norm(fp2_neg(qy));
+      Fp2 qx = fp2_load_mem(ws_at(p, 18));
+      px = fp_load_mem(p); py = fp_load_mem(ws_at(p, 9));
+      T = g2j_load(park);
+      BN_SCHED_BARRIER;
+      l = addition_step(T, qx, fp2_select(d > 0, qy, nqy));
+      g2j_store(park, T);
+      BN_MEM_FENCE;
+      f = ell(f, l, px, py);
+    }
+  }
+  BN_OPAQUE(p); BN_OPAQUE(park);
+  Fp2 g2 = fp2_const(bnc::GAMMA1[1]), g3 = fp2_const(bnc::GAMMA1[2]);
+  Fp2 q1x = fp2_mul(fp2_norm(fp2_conj(fp2_load_mem(ws_at(p, 18)))), g2);
+  Fp2 q1y = fp2_mul(fp2_norm(fp2_conj(fp2_load_mem(ws_at(p, 36)))), g3);
+  Fp2 q2x = fp2_mul(fp2_norm(fp2_conj(q1x)), g2);
+  Fp2 q2y = fp2_norm(fp2_neg(fp2_mul(fp2_norm(fp2_conj(q1y)), g3)));
+  G2J T = g2j_load(park);
+  Line l = addition_step(T, q1x, q1y);
+  BN_OPAQUE(p);
+  f = ell(f, l, fp_load_mem(p), fp_load_mem(ws_at(p, 9)));
+  l = addition_step(T, q2x, q2y);
+  BN_OPAQUE(p);
+  f = ell(f, l, fp_load_mem(p), fp_load_mem(ws_at(p, 9)));
+  return f;
+}
+
 // Two VARIABLE pairs per lane sharing one f^2 per digit (multi_miller_loop, pairings.rs:808-857: "one shared f.square()
 // per bit for all terms"): f = ML(Ha, Qa) * ML(Hb, Qb), bit-identical to the product of the two one-pair loops because the
 // arithmetic is exact.  Used by aggregate verify (k_miller_hpk2.hip).  Register budget = that of the verify loop: only ONE

@@ -45,6 +45,48 @@ void hs_miller1(const uint8_t* g1, const uint8_t* g2, uint8_t* out, int* status)
   *status = st;
   fp12_to_be(out, f);
 }
+// the parked loops of the device kernels on host memory (stride 1): one pair (k_miller_1), two variable pairs sharing f^2
+// (k_miller_hpk2), prepared keys (k_g2_prepare + k_g2_expand + k_miller_prepared, and two prepared pairs: k_miller_hpk2p)
+void hs_miller1_ws(const uint8_t* g1, const uint8_t* g2, uint8_t* out) {
+  bool o1, o2;
+  G1A p = g1_decode(g1, o1); G2A q = g2_decode(g2, o2);
+  static int32_t mem[108];
+  const Ws ws = {mem, 1, 0, false};
+  fp_store_mem(ws, fp_norm(p.x)); fp_store_mem(ws_at(ws, 9), fp_norm(p.y));
+  fp2_store_mem(ws_at(ws, 18), fp2_norm(q.x)); fp2_store_mem(ws_at(ws, 36), fp2_norm(q.y));
+  fp12_to_be(out, miller_loop_1_ws(ws, ws_at(ws, 54)));
+}
+// ML(Ha, Qa) * ML(Hb, Qb): by the two-variable-pair loop (out1), by prepared raw tables (out2); live_b = 0 pads the second pair
+void hs_miller2(const uint8_t* ha, const uint8_t* qa, const uint8_t* hb, const uint8_t* qb, int live_b, uint8_t* out1, uint8_t* out2) {
+  bool ok;
+  G1A Ha = g1_decode(ha, ok), Hb = g1_decode(hb, ok);
+  G2A Qa = g2_decode(qa, ok), Qb = g2_decode(qb, ok);
+  static int32_t hh[36], qw[72], park[54], lpark[54], ta[88 * 54], tb[88 * 54];
+  const Ws whh = {hh, 1, 0, false}, wqw = {qw, 1, 0, false};
+  fp_store_mem(whh, fp_norm(Ha.x)); fp_store_mem(ws_at(whh, 9), fp_norm(Ha.y));
+  fp_store_mem(ws_at(whh, 18), fp_norm(Hb.x)); fp_store_mem(ws_at(whh, 27), live_b ? fp_norm(Hb.y) : fp_one());
+  fp2_store_mem(wqw, fp2_norm(Qa.x)); fp2_store_mem(ws_at(wqw, 18), fp2_norm(Qa.y));
+  fp2_store_mem(ws_at(wqw, 36), fp2_norm(Qb.x)); fp2_store_mem(ws_at(wqw, 54), fp2_norm(Qb.y));
+  fp12_to_be(out1, miller_loop_2var_ws(whh, wqw, Ws{park, 1, 0, false}, Ws{lpark, 1, 0, false}, true, live_b != 0));
+  g2_prepare_lines(Qa, Ws{ta, 1, 0, false}); g2_prepare_lines(Qb, Ws{tb, 1, 0, false});
+  fp12_to_be(out2, miller_loop_2prepared(whh, Ws{ta, 1, 0, false}, Ws{tb, 1, 0, false}, true, live_b != 0));
+}
+// ML(sig, -G2gen) * ML(H, pk) by the pair tables of the prepared-key verify path
+void hs_miller_prepared(const uint8_t* sig, const uint8_t* h, const uint8_t* pk, uint8_t* out) {
+  bool ok;
+  G1A S = g1_decode(sig, ok), H = g1_decode(h, ok);
+  G2A Q = g2_decode(pk, ok);
+  static int32_t raw[88 * 54], exp_[88 * 162], inv[72];
+  g2_prepare_lines(Q, Ws{raw, 1, 0, false});
+  for (int t = 0; t < 88; ++t)
+    line_pair_expand(line_from_table(BN_NEG_G2_LINE_TABLE[t]), line_load_limbs(Ws{raw + 54 * t, 1, 0, false}), Ws{exp_ + 162 * t, 1, 0, false});
+  const Ws w = {inv, 1, 0, false};
+  Fp xs = fp_norm(S.x), ys = fp_norm(S.y), xh = fp_norm(H.x), yh = fp_norm(H.y);
+  fp_store_mem(w, xs); fp_store_mem(ws_at(w, 9), ys); fp_store_mem(ws_at(w, 18), xh); fp_store_mem(ws_at(w, 27), yh);
+  fp_store_mem(ws_at(w, 36), fp_mul(ys, yh)); fp_store_mem(ws_at(w, 45), fp_mul(xs, xh));
+  fp_store_mem(ws_at(w, 54), fp_mul(ys, xh)); fp_store_mem(ws_at(w, 63), fp_mul(xs, yh));
+  fp12_to_be(out, miller_loop_prepared(w, Ws{exp_, 1, 0, false}));
+}
 int hs_final_exp(const uint8_t* in, uint8_t* out) {
   bool ok;
   Fp12 f = fp12_from_be(in, ok);

@@ -188,3 +188,26 @@ def test_glv_split_and_endomorphism(hs, oracle, pyref):
         p = oracle.g1_mul(G1, rnd.randrange(1, R))
         hs.hs_glv_phi(p, o64)
         assert o64.raw == oracle.g1_mul(p, lam)
+
+
+def test_parked_and_prepared_miller_loops(hs, oracle, pyref):
+    """The loops behind k_miller_1 (invariants and T parked), k_miller_hpk2 (two variable pairs sharing f^2), k_miller_hpk2p
+    (two prepared pairs) and k_miller_prepared (pair tables: key line x -G2gen line) on the host with the interval checker:
+    every one of them produces the oracle's Miller value bit for bit."""
+    rnd = random.Random(21)
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    neg_g2 = pyref.g2_to_bytes(pyref.g2_neg(pyref.G2_GEN))
+    o1 = ctypes.create_string_buffer(384); o2 = ctypes.create_string_buffer(384)
+    for _ in range(2):
+        ha, hb, sig = (oracle.g1_mul(G1, rnd.randrange(1, pyref.R)) for _ in range(3))
+        qa, qb = (oracle.g2_mul(G2, rnd.randrange(1, pyref.R)) for _ in range(2))
+        hs.hs_miller1_ws(ha, qa, o1)
+        assert o1.raw == oracle.miller_loop_batch(ha, qa, 1)
+        hs.hs_miller2(ha, qa, hb, qb, 1, o1, o2)
+        want = oracle.multi_miller_loop(ha + hb, qa + qb, 2)
+        assert o1.raw == want and o2.raw == want
+        hs.hs_miller2(ha, qa, hb, qb, 0, o1, o2)                 # second pair is padding: contributes exactly 1
+        want = oracle.multi_miller_loop(ha, qa, 1)
+        assert o1.raw == want and o2.raw == want
+        hs.hs_miller_prepared(sig, ha, qa, o1)
+        assert o1.raw == oracle.multi_miller_loop(sig + ha, neg_g2 + qa, 2)
