@@ -598,8 +598,10 @@ int blsbn254_verify_batch_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8
   }
   return 0;
 }
+static int fp12_tree(blsbn254_ctx* c, int32_t* a, size_t cnt, size_t sa, int32_t** res, size_t* rs);
+
 // ---------------- G2Prepared: explicit API
-struct blsbn254_g2prepared { blsbn254_ctx* ctx; size_t u; DevBuf table, ok; };
+struct blsbn254_g2prepared { blsbn254_ctx* ctx; size_t u; DevBuf table, raw, ok; };   // pair tables (verify), raw line triples (multi_miller_loop), validity
 int blsbn254_g2_prepare_batch(blsbn254_ctx* c, const uint8_t* pks, size_t u, blsbn254_g2prepared** out) {
   if (!c || !out || (u && !pks)) return BLSBN254_E_ARG;
   *out = nullptr;
@@ -608,12 +610,11 @@ int blsbn254_g2_prepare_batch(blsbn254_ctx* c, const uint8_t* pks, size_t u, bls
   blsbn254_g2prepared* p = new blsbn254_g2prepared();
   p->ctx = c; p->u = u;
   if (u) {
-    hipError_t e1 = p->table.reserve(u * PREP_KEY_LIMBS * 4), e2 = p->ok.reserve(u), e3 = c->in_a.reserve(128 * u);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { p->table.release(); p->ok.release(); delete p; return BLSBN254_E_NOMEM; }
+    hipError_t e1 = p->table.reserve(u * PREP_KEY_LIMBS * 4), e2 = p->ok.reserve(u), e3 = c->in_a.reserve(128 * u), e4 = p->raw.reserve(u * PREP_RAW_LIMBS * 4);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) { p->table.release(); p->raw.release(); p->ok.release(); delete p; return BLSBN254_E_NOMEM; }
     HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * u, hipMemcpyHostToDevice, c->stream));
-    if (c->prep_raw.reserve(u * PREP_RAW_LIMBS * 4) != hipSuccess) { p->table.release(); p->ok.release(); delete p; return BLSBN254_E_NOMEM; }
-    LAUNCH(c, "g2_prepare", k_g2_prepare, u, (const uint8_t*)c->in_a.p, (const uint32_t*)nullptr, (uint32_t)u, (int32_t*)c->prep_raw.p, (uint8_t*)p->ok.p);
-    LAUNCH(c, "g2_expand", k_g2_expand, u * (size_t)BN_NEG_G2_LINES, (const int32_t*)c->prep_raw.p, (uint32_t)u, (int32_t*)p->table.p);
+    LAUNCH(c, "g2_prepare", k_g2_prepare, u, (const uint8_t*)c->in_a.p, (const uint32_t*)nullptr, (uint32_t)u, (int32_t*)p->raw.p, (uint8_t*)p->ok.p);
+    LAUNCH(c, "g2_expand", k_g2_expand, u * (size_t)BN_NEG_G2_LINES, (const int32_t*)p->raw.p, (uint32_t)u, (int32_t*)p->table.p);
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   *out = p;
@@ -623,7 +624,7 @@ void blsbn254_g2prepared_destroy(blsbn254_g2prepared* p) {
   if (!p) return;
   (void)hipSetDevice(p->ctx->device);
   (void)hipStreamSynchronize(p->ctx->stream);
-  p->table.release(); p->ok.release();
+  p->table.release(); p->raw.release(); p->ok.release();
   delete p;
 }
 size_t blsbn254_g2prepared_count(const blsbn254_g2prepared* p) { return p ? p->u : 0; }
@@ -658,6 +659,47 @@ int blsbn254_verify_batch_prepared(blsbn254_ctx* c, const blsbn254_g2prepared* k
     if (rc) return rc;
   }
   HIPCHK(c, hipMemcpyAsync(bm, c->bitmap.p, nb, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+// multi_miller_loop(&[(&G1Affine, &G2Prepared)]) (pairings.rs:808-857) over prepared keys named by index: the Fp12 product of
+// the n Miller values, two pairs per lane sharing f^2, every line read from the keys' tables.  A pair whose G1 member is
+// the identity contributes 1 (the reference skips such terms); every referenced key must be valid (else InvalidG2Bytes).
+int blsbn254_multi_miller_loop_prepared(blsbn254_ctx* c, const blsbn254_g2prepared* keys, const uint32_t* key_idx, const uint8_t* g1, size_t n,
+                                        uint8_t ml_out[384]) {
+  if (!c || !keys || keys->ctx != c || !ml_out || (n && (!key_idx || !g1))) return BLSBN254_E_ARG;
+  if (n == 0) { std::memset(ml_out, 0, 384); ml_out[31] = 1; return 0; }
+  CHECK_LANES(c, n);
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t n_lanes = (n + 1) / 2;
+  HIPCHK(c, c->in_a.reserve(64 * n)); HIPCHK(c, c->kd_kid.reserve(4 * n)); HIPCHK(c, c->h_ws.reserve(n * 18 * 4)); HIPCHK(c, c->f_ws.reserve(n_lanes * 108 * 4));
+  HIPCHK(c, c->status.reserve(n)); HIPCHK(c, c->flags.reserve(n)); HIPCHK(c, c->kd_hist.reserve(4 * (keys->u + 1))); HIPCHK(c, c->misc.reserve(64)); HIPCHK(c, c->out.reserve(384));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, g1, 64 * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->kd_kid.p, key_idx, 4 * n, hipMemcpyHostToDevice, c->stream));
+  // key indices in range?
+  int* d_bad = (int*)c->misc.p;
+  static const int init = 0x7fffffff;
+  HIPCHK(c, hipMemcpyAsync(d_bad, &init, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->kd_hist.p, 0, 4 * keys->u, c->stream));
+  LAUNCH(c, "kd_hist", k_kd_hist, n, (const uint32_t*)c->kd_kid.p, (uint32_t)n, (uint32_t)keys->u, (uint32_t*)c->kd_hist.p, d_bad);
+  int bad;
+  HIPCHK(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (bad != 0x7fffffff) { c->last_error = "key index out of range at pair " + std::to_string(bad); return BLSBN254_E_ARG; }
+  LAUNCH(c, "g1_to_ws", k_g1_to_ws_batch, n, (const uint8_t*)c->in_a.p, n, (int32_t*)c->h_ws.p, (uint8_t*)c->status.p);
+  int rc = first_bad(c, (const uint8_t*)c->status.p, n, 1, 1, &bad);
+  if (rc) return rc;
+  if (bad >= 0) return BLSBN254_ERR_G1;
+  LAUNCH(c, "miller_hpk2p", k_miller_hpk2p, n_lanes, (const int32_t*)c->h_ws.p, n, (const uint32_t*)c->kd_kid.p, (const int32_t*)keys->raw.p,
+         (const uint8_t*)keys->ok.p, n, (int32_t*)c->f_ws.p, n_lanes, (uint8_t*)c->flags.p, (const uint8_t*)c->status.p);
+  rc = first_bad(c, (const uint8_t*)c->flags.p, n, 1, 1, &bad);
+  if (rc) return rc;
+  if (bad >= 0) return BLSBN254_ERR_G2;
+  int32_t* res; size_t rs;
+  rc = fp12_tree(c, (int32_t*)c->f_ws.p, n_lanes, n_lanes, &res, &rs);
+  if (rc) return rc;
+  LAUNCH(c, "fp12_to_bytes", k_fp12_to_bytes, 1, (const int32_t*)res, (size_t)1, rs, (uint8_t*)c->out.p);
+  HIPCHK(c, hipMemcpyAsync(ml_out, c->out.p, 384, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return 0;
 }
@@ -849,7 +891,7 @@ static int aggregate_partial_impl(blsbn254_ctx* c, const uint8_t* pks, const uin
     // table once, beside hash-to-G1; the pairs read their lines from those tables
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
     LAUNCH(c, "miller_hpk2p", k_miller_hpk2p, n_lanes, (const int32_t*)c->h_ws.p, np, (const uint32_t*)c->kd_kid.p, (const int32_t*)c->prep_raw.p,
-           (const uint8_t*)c->prep_ok.p, np, f, n_lanes, (uint8_t*)c->flags.p);
+           (const uint8_t*)c->prep_ok.p, np, f, n_lanes, (uint8_t*)c->flags.p, (const uint8_t*)nullptr);
     if (n) { LAUNCH(c, "and_reduce", k_and_reduce, n, (const uint8_t*)c->flags.p, (const uint8_t*)c->flags.p, n, d_ok); }
   } else {
     LAUNCH(c, "miller_hpk2", k_miller_hpk2, n_lanes, (const int32_t*)c->h_ws.p, (const uint8_t*)c->in_a.p, np, (int32_t*)c->q_ws.p, f, n_lanes, (uint8_t*)c->flags.p);

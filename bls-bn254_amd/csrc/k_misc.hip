@@ -62,6 +62,18 @@ BN_KERNEL k_g1_to_ws(const uint8_t* g1, int32_t* h_ws, size_t slot, size_t strid
   store_fp(h_ws + slot, stride, fp_select(good, p.x, gp.x)); store_fp(h_ws + 9 * stride + slot, stride, fp_select(good, p.y, gp.y));
   *ok = good ? 1 : 0;
 }
+// n G1 points (64 bytes each) -> affine Montgomery limbs in a limb-major H workspace (stride n); status bit 0: decodes,
+// bit 1: is the identity (such a pair contributes 1 to a Miller product and is replaced by the generator here)
+BN_KERNEL k_g1_to_ws_batch(const uint8_t* g1, size_t n, int32_t* h_ws, uint8_t* status) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool okd;
+  G1A p = g1_decode(g1 + 64 * i, okd);
+  const bool use = okd & !p.inf;
+  G1A gp; gp.x = fp_one(); gp.y = fp_norm(fp_add(fp_one(), fp_one()));
+  store_fp(h_ws + i, n, fp_select(use, p.x, gp.x)); store_fp(h_ws + 9 * n + i, n, fp_select(use, p.y, gp.y));
+  status[i] = (uint8_t)((okd ? 1 : 0) | (p.inf ? 2 : 0));
+}
 BN_KERNEL k_g1_add_pairs(const int32_t* in, size_t n_in, size_t in_stride, int32_t* out, size_t out_stride) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t n_out = (n_in + 1) >> 1;

@@ -219,6 +219,18 @@ class Engine:
                                                            off.ctypes.data_as(_u64p), ps, ctypes.c_size_t(n), pd, ctypes.c_size_t(len(dst)), po))
         return o[:(n + 7) // 8].tobytes()
 
+    def multi_miller_loop_prepared(self, keys, key_idx, g1, n):
+        """multi_miller_loop over (G1 point, prepared key) terms (pairings.rs:808-857): 384-byte Miller product."""
+        idx = np.ascontiguousarray(np.asarray(key_idx, dtype=np.uint32))
+        if idx.size != n:
+            raise ValueError("one key index per pair")
+        if idx.size == 0:
+            idx = np.zeros(1, dtype=np.uint32)
+        a, pa = _inbuf(g1, 64 * n); o, po = _outbuf(384)
+        self._chk(self._lib.blsbn254_multi_miller_loop_prepared(self._ctx, keys._h, idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), pa,
+                                                                ctypes.c_size_t(n), po))
+        return o.tobytes()
+
     def verify_batch_rlc(self, pks, msgs, sigs, dst=DEFAULT_DST, seed=None):
         """Same bitmap as verify_batch, via random linear combinations (one final exponentiation per 16 tuples,
         exact re-verification of failing groups).  seed = None: the library draws it from the OS inside the call

@@ -121,6 +121,12 @@ int blsbn254_g2prepared_valid(blsbn254_ctx* ctx, const blsbn254_g2prepared* keys
 int blsbn254_verify_batch_prepared(blsbn254_ctx* ctx, const blsbn254_g2prepared* keys, const uint32_t* key_idx,
                                    const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs, size_t n,
                                    const uint8_t* dst, size_t dst_len, uint8_t* valid_bitmap);
+/* multi_miller_loop(&[(&G1Affine, &G2Prepared)]) -> MillerLoopResult (pairings.rs:808-857) with the second members given as
+ * prepared keys by index: the 384-byte product of the n Miller values (same bytes as blsbn254_multi_miller_loop on the
+ * plain points).  A pair whose G1 member is the identity is skipped, as in the reference; a G1 that does not decode
+ * returns BLSBN254_ERR_G1, a referenced key that is not a valid G2 point returns BLSBN254_ERR_G2. */
+int blsbn254_multi_miller_loop_prepared(blsbn254_ctx* ctx, const blsbn254_g2prepared* keys, const uint32_t* key_idx,
+                                        const uint8_t* g1 /* n*64 */, size_t n, uint8_t ml_out[384]);
 /* The same check split for sharding over GPUs: every rank reduces ITS (pk_i, msg_i) to one
  * Fp12 partial product prod_i ML(H(msg_i), pk_i) (384 B; n = 0 gives Fp12::ONE) and reports whether all its
  * public keys validated; the partials are exchanged (all-gather of 384-byte records, Fp12 multiplication is

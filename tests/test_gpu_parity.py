@@ -719,3 +719,29 @@ def test_aggregate_with_repeated_keys_prepared_path(eng, oracle, M, n, pool):
         assert eng.aggregate_verify(pks, bad, agg, dst) is False
         assert eng.aggregate_verify(pks[:128 * (n - 1)] + synth.NON_SUBGROUP_PK, msgs, agg, dst) is False
     eng.set_auto_prepare(True)
+
+
+def test_multi_miller_loop_over_prepared_keys(eng, oracle, pyref, M):
+    """multi_miller_loop(&[(&G1Affine, &G2Prepared)]) with the G2 side prepared once (G2Prepared::from, pairings.rs:609-660,
+    which panics in the reference: E6): same 384 bytes as the plain multi_miller_loop of the oracle; identity G1 terms are
+    skipped; odd and even term counts."""
+    rnd = random.Random(77)
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    keys = [oracle.g2_mul(G2, rnd.randrange(1, pyref.R)) for _ in range(6)]
+    prep = eng.g2_prepare_batch(b"".join(keys), len(keys))
+    for n in (1, 2, 5, 64, 333):
+        idx = [rnd.randrange(len(keys)) for _ in range(n)]
+        pts = [oracle.g1_mul(G1, rnd.randrange(1, pyref.R)) for _ in range(min(n, 12))]
+        g1 = [pts[rnd.randrange(len(pts))] for _ in range(n)]
+        if n >= 5:
+            g1[3] = IDENT1                                            # skipped term
+        got = eng.multi_miller_loop_prepared(prep, idx, b"".join(g1), n)
+        assert got == oracle.multi_miller_loop(b"".join(g1), b"".join(keys[k] for k in idx), n)
+        assert got == eng.multi_miller_loop(b"".join(g1), b"".join(keys[k] for k in idx), n)
+    assert eng.multi_miller_loop_prepared(prep, [], b"", 0) == ONE_GT
+    bad = eng.g2_prepare_batch(keys[0] + synth.NON_SUBGROUP_PK, 2)
+    with pytest.raises(M.InvalidG2Bytes):
+        eng.multi_miller_loop_prepared(bad, [0, 1], g1[0] + g1[0], 2)
+    with pytest.raises(M.InvalidG1Bytes):
+        eng.multi_miller_loop_prepared(prep, [0], b"\xff" * 64, 1)
+    prep.close(); bad.close()
