@@ -509,12 +509,7 @@ static int verify_prepared_dev(blsbn254_ctx* c, const int32_t* table, const uint
   HIPCHK(c, c->kd_hist.reserve(4 * (u + 1))); HIPCHK(c, c->kd_cursor.reserve(4 * (u + 1))); HIPCHK(c, c->kd_perm.reserve(4 * n));
   HIPCHK(c, c->prep_isone.reserve(n)); HIPCHK(c, c->prep_valid.reserve(n)); HIPCHK(c, c->misc.reserve(64));
   uint32_t* hist = (uint32_t*)c->kd_hist.p; uint32_t* cursor = (uint32_t*)c->kd_cursor.p; uint32_t* perm = (uint32_t*)c->kd_perm.p;
-  // 64-lane workgroups: the per-key preparation holds a few CUs on the second stream meanwhile, and 1024 workgroups of 256
-  // lanes on 252 CUs at 2 per CU would run a nearly empty third round (4.6 instead of 3.8 ms); the kernel has no LDS / barriers
-  { ProfScope ps_(c, "hash_to_g1");
-    hipLaunchKernelGGL(k_hash_to_g1, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, c->stream, d_msgs, d_off, n, (const uint8_t*)c->dst.p, dl,
-                       (int32_t*)c->h_ws.p, n, (uint8_t*)nullptr, 0); }
-  HIPCHK(c, hipGetLastError());
+  LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, d_msgs, d_off, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, n, (uint8_t*)nullptr, 0);
   if (!hist_done) {
     int* d_bad = (int*)c->misc.p;
     static const int init = 0x7fffffff;
