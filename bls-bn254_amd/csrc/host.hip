@@ -600,18 +600,19 @@ struct blsbn254_g2prepared { blsbn254_ctx* ctx; size_t u; DevBuf table, raw, ok;
 int blsbn254_g2_prepare_batch(blsbn254_ctx* c, const uint8_t* pks, size_t u, blsbn254_g2prepared** out) {
   if (!c || !out || (u && !pks)) return BLSBN254_E_ARG;
   *out = nullptr;
-  if (u > PREP_MAX_KEYS) { c->last_error = "more than 65536 keys in one prepared table"; return BLSBN254_E_ARG; }
+  if (u + 1 > PREP_MAX_KEYS) { c->last_error = "more than 65535 keys in one prepared table"; return BLSBN254_E_ARG; }
   HIPCHK(c, hipSetDevice(c->device));
   blsbn254_g2prepared* p = new blsbn254_g2prepared();
   p->ctx = c; p->u = u;
-  if (u) {
-    hipError_t e1 = p->table.reserve(u * PREP_KEY_LIMBS * 4), e2 = p->ok.reserve(u), e3 = c->in_a.reserve(128 * u), e4 = p->raw.reserve(u * PREP_RAW_LIMBS * 4);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) { p->table.release(); p->raw.release(); p->ok.release(); delete p; return BLSBN254_E_NOMEM; }
-    HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * u, hipMemcpyHostToDevice, c->stream));
-    LAUNCH(c, "g2_prepare", k_g2_prepare, u, (const uint8_t*)c->in_a.p, (const uint32_t*)nullptr, (uint32_t)u, (int32_t*)p->raw.p, (uint8_t*)p->ok.p);
-    LAUNCH(c, "g2_expand", k_g2_expand, u * (size_t)BN_NEG_G2_LINES, (const int32_t*)p->raw.p, (uint32_t)u, (int32_t*)p->table.p);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-  }
+  // entry u (one past the caller's keys) is -G2gen: the second member of the aggregate signature's pair
+  const size_t u1 = u + 1;
+  hipError_t e1 = p->table.reserve(u1 * PREP_KEY_LIMBS * 4), e2 = p->ok.reserve(u1), e3 = c->in_a.reserve(128 * u1), e4 = p->raw.reserve(u1 * PREP_RAW_LIMBS * 4);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) { p->table.release(); p->raw.release(); p->ok.release(); delete p; return BLSBN254_E_NOMEM; }
+  if (u) HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * u, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync((uint8_t*)c->in_a.p + 128 * u, NEG_G2_BYTES, 128, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "g2_prepare", k_g2_prepare, u1, (const uint8_t*)c->in_a.p, (const uint32_t*)nullptr, (uint32_t)u1, (int32_t*)p->raw.p, (uint8_t*)p->ok.p);
+  LAUNCH(c, "g2_expand", k_g2_expand, u1 * (size_t)BN_NEG_G2_LINES, (const int32_t*)p->raw.p, (uint32_t)u1, (int32_t*)p->table.p);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   *out = p;
   return 0;
 }
@@ -696,6 +697,52 @@ int blsbn254_multi_miller_loop_prepared(blsbn254_ctx* c, const blsbn254_g2prepar
   LAUNCH(c, "fp12_to_bytes", k_fp12_to_bytes, 1, (const int32_t*)res, (size_t)1, rs, (uint8_t*)c->out.p);
   HIPCHK(c, hipMemcpyAsync(ml_out, c->out.p, 384, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
+// CoreAggregateVerify with the public keys given as prepared keys by index: prod_i e(H(msg_i), pk_[key_idx_i]) * e(agg_sig, -G2gen) == 1.
+// The signature's pair uses the table's own -G2gen entry; two pairs per lane, every line from the tables, ONE final exponentiation.
+int blsbn254_aggregate_verify_prepared(blsbn254_ctx* c, const blsbn254_g2prepared* keys, const uint32_t* key_idx, const uint8_t* msgs, const uint64_t* off,
+                                       size_t n, const uint8_t agg_sig[64], const uint8_t* dst, size_t dst_len, int* valid) {
+  if (!c || !keys || keys->ctx != c || !valid || !agg_sig || !off || (n && !key_idx) || (dst_len && !dst)) return BLSBN254_E_ARG;
+  *valid = 0;
+  if (n == 0) return 0;
+  const size_t np = n + 1, n_lanes = (np + 1) / 2;
+  CHECK_LANES(c, np);
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
+  if (rc) return rc;
+  rc = stage_msgs(c, msgs, off, n);
+  if (rc) return rc;
+  HIPCHK(c, c->in_b.reserve(64)); HIPCHK(c, c->kd_kid.reserve(4 * np)); HIPCHK(c, c->h_ws.reserve(np * 18 * 4)); HIPCHK(c, c->f_ws.reserve(n_lanes * 108 * 4));
+  HIPCHK(c, c->flags.reserve(np)); HIPCHK(c, c->kd_hist.reserve(4 * (keys->u + 2))); HIPCHK(c, c->misc.reserve(64));
+  const uint32_t sig_key = (uint32_t)keys->u;
+  HIPCHK(c, hipMemcpyAsync(c->kd_kid.p, key_idx, 4 * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync((uint32_t*)c->kd_kid.p + n, &sig_key, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->in_b.p, agg_sig, 64, hipMemcpyHostToDevice, c->stream));
+  int* d_ok = (int*)c->misc.p;               // [0] first bad key index (kd_hist), [1] all keys valid, [2] (byte) signature valid
+  static const int init[3] = {0x7fffffff, 1, 1};
+  HIPCHK(c, hipMemcpyAsync(d_ok, init, 12, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->kd_hist.p, 0, 4 * keys->u, c->stream));
+  LAUNCH(c, "kd_hist", k_kd_hist, n, (const uint32_t*)c->kd_kid.p, (uint32_t)n, (uint32_t)keys->u, (uint32_t*)c->kd_hist.p, d_ok);
+  int bad;
+  HIPCHK(c, hipMemcpyAsync(&bad, d_ok, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));          // also: sig_key is on the stack
+  if (bad != 0x7fffffff) { c->last_error = "key index out of range at pair " + std::to_string(bad); return BLSBN254_E_ARG; }
+  LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, np, (uint8_t*)nullptr, 0);
+  LAUNCH(c, "g1_to_ws", k_g1_to_ws, 1, (const uint8_t*)c->in_b.p, (int32_t*)c->h_ws.p, n, np, (uint8_t*)(d_ok + 2));
+  LAUNCH(c, "miller_hpk2p", k_miller_hpk2p, n_lanes, (const int32_t*)c->h_ws.p, np, (const uint32_t*)c->kd_kid.p, (const int32_t*)keys->raw.p,
+         (const uint8_t*)keys->ok.p, np, (int32_t*)c->f_ws.p, n_lanes, (uint8_t*)c->flags.p, (const uint8_t*)nullptr);
+  LAUNCH(c, "and_reduce", k_and_reduce, n, (const uint8_t*)c->flags.p, (const uint8_t*)c->flags.p, n, d_ok + 1);
+  int32_t* res; size_t rs;
+  rc = fp12_tree(c, (int32_t*)c->f_ws.p, n_lanes, n_lanes, &res, &rs);
+  if (rc) return rc;
+  int* d_one = d_ok + 4;
+  rc = run_final_exp(c, res, 1, rs, 3, nullptr, nullptr, nullptr, nullptr, d_one);
+  if (rc) return rc;
+  int h[5] = {0, 0, 0, 0, 0};
+  HIPCHK(c, hipMemcpyAsync(h, d_ok, 20, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *valid = (h[1] == 1 && (h[2] & 0xff) == 1 && h[4] == 1) ? 1 : 0;
   return 0;
 }
 // how many verify chunks took the prepared-key path / the exact per-tuple path on this context (tests, bench)

@@ -231,6 +231,21 @@ class Engine:
                                                                 ctypes.c_size_t(n), po))
         return o.tobytes()
 
+    def aggregate_verify_prepared(self, keys, key_idx, msgs, agg_sig, dst=DEFAULT_DST):
+        n = len(msgs)
+        data, off = pack_messages(msgs)
+        idx = np.ascontiguousarray(np.asarray(key_idx, dtype=np.uint32))
+        if idx.size != n:
+            raise ValueError("one key index per pair")
+        if idx.size == 0:
+            idx = np.zeros(1, dtype=np.uint32)
+        m, pm = _inbuf(data); s, ps = _inbuf(agg_sig, 64); d, pd = _inbuf(dst)
+        valid = ctypes.c_int(0)
+        self._chk(self._lib.blsbn254_aggregate_verify_prepared(self._ctx, keys._h, idx.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), pm,
+                                                               off.ctypes.data_as(_u64p), ctypes.c_size_t(n), ps, pd, ctypes.c_size_t(len(dst)),
+                                                               ctypes.byref(valid)))
+        return bool(valid.value)
+
     def verify_batch_rlc(self, pks, msgs, sigs, dst=DEFAULT_DST, seed=None):
         """Same bitmap as verify_batch, via random linear combinations (one final exponentiation per 16 tuples,
         exact re-verification of failing groups).  seed = None: the library draws it from the OS inside the call

@@ -127,6 +127,11 @@ int blsbn254_verify_batch_prepared(blsbn254_ctx* ctx, const blsbn254_g2prepared*
  * returns BLSBN254_ERR_G1, a referenced key that is not a valid G2 point returns BLSBN254_ERR_G2. */
 int blsbn254_multi_miller_loop_prepared(blsbn254_ctx* ctx, const blsbn254_g2prepared* keys, const uint32_t* key_idx,
                                         const uint8_t* g1 /* n*64 */, size_t n, uint8_t ml_out[384]);
+/* blsbn254_aggregate_verify with the public keys named by index into a prepared table: only 4 bytes per pair cross the
+ * boundary instead of 128, and no key is validated or turned into lines again.  Same preconditions as aggregate_verify. */
+int blsbn254_aggregate_verify_prepared(blsbn254_ctx* ctx, const blsbn254_g2prepared* keys, const uint32_t* key_idx,
+                                       const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t agg_sig[64],
+                                       const uint8_t* dst, size_t dst_len, int* valid);
 /* The same check split for sharding over GPUs: every rank reduces ITS (pk_i, msg_i) to one
  * Fp12 partial product prod_i ML(H(msg_i), pk_i) (384 B; n = 0 gives Fp12::ONE) and reports whether all its
  * public keys validated; the partials are exchanged (all-gather of 384-byte records, Fp12 multiplication is

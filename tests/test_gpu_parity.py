@@ -709,6 +709,19 @@ def test_aggregate_with_repeated_keys_prepared_path(eng, oracle, M, n, pool):
             acc = oracle.g1_add(acc, h[64 * i:64 * i + 64])
         agg = oracle.g1_add(agg, oracle.g1_mul(acc, sks[k]))
     want = oracle.multi_miller_loop(h, pks, n)
+    # the explicit form: keys prepared once, pairs name their key by index (4 bytes per pair instead of 128)
+    prep = eng.g2_prepare_batch(b"".join(pkp) + synth.NON_SUBGROUP_PK, pool + 1)
+    kidx = [i % pool for i in range(n)]
+    assert eng.aggregate_verify_prepared(prep, kidx, msgs, agg, dst) is True
+    badm = list(msgs); badm[n // 3] = b"tampered"
+    assert eng.aggregate_verify_prepared(prep, kidx, badm, agg, dst) is False
+    assert eng.aggregate_verify_prepared(prep, kidx[:-1] + [pool], msgs, agg, dst) is False        # a key outside the subgroup
+    assert eng.aggregate_verify_prepared(prep, kidx, msgs, IDENT1, dst) is False                    # identity signature
+    assert eng.aggregate_verify_prepared(prep, [], [], agg, dst) is False
+    with pytest.raises(M.Bn254Error) as e:
+        eng.aggregate_verify_prepared(prep, kidx[:-1] + [pool + 1], msgs, agg, dst)                 # index of the table's own -G2gen entry / out of range
+    assert e.value.code == -1
+    prep.close()
     for auto in (True, False):
         eng.set_auto_prepare(auto)
         part, ok = eng.aggregate_partial(pks, msgs, dst)
