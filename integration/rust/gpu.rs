@@ -208,6 +208,49 @@ pub fn threshold_combine(ids: &[[u8; 32]], partials: &[[u8; 64]]) -> Result<[u8;
     Ok(out)
 }
 
+// ---------------------------------------------------------------- repeated signers: keys prepared once (G2Prepared, batched)
+
+/// The line tables of a set of public keys, resident on the GPU (`blsbn254_g2prepared`): what `G2Prepared::from`
+/// (`pairings.rs:614-660`) computes per key, for a whole validator set at once.  Tied to the process-wide engine context.
+pub struct PreparedKeys(*mut ffi::PreparedKeys);
+unsafe impl Send for PreparedKeys {}
+
+impl PreparedKeys {
+    pub fn new(pks: &[[u8; 128]]) -> Self {
+        let flat: Vec<u8> = pks.iter().flatten().copied().collect();
+        let mut h: *mut ffi::PreparedKeys = core::ptr::null_mut();
+        with_ctx(|c| check(unsafe { ffi::blsbn254_g2_prepare_batch(c, flat.as_ptr(), pks.len(), &mut h) })).expect("device error");
+        PreparedKeys(h)
+    }
+    pub fn len(&self) -> usize { unsafe { ffi::blsbn254_g2prepared_count(self.0) } }
+}
+impl Drop for PreparedKeys {
+    fn drop(&mut self) { let _g = engine().lock(); unsafe { ffi::blsbn254_g2prepared_destroy(self.0) } }
+}
+
+/// `verify_batch` against prepared keys: tuple i was signed under key `key_idx[i]`.
+pub fn verify_batch_prepared(keys: &PreparedKeys, key_idx: &[u32], msgs: &[&[u8]], sigs: &[[u8; 64]], dst: &[u8]) -> Vec<bool> {
+    assert!(key_idx.len() == msgs.len() && msgs.len() == sigs.len());
+    let n = msgs.len();
+    let (data, off) = pack(msgs);
+    let sg: Vec<u8> = sigs.iter().flatten().copied().collect();
+    let mut bm = vec![0u8; (n + 7) / 8];
+    with_ctx(|c| check(unsafe {
+        ffi::blsbn254_verify_batch_prepared(c, keys.0, key_idx.as_ptr(), data.as_ptr(), off.as_ptr(), sg.as_ptr(), n, dst.as_ptr(), dst.len(), bm.as_mut_ptr())
+    }))
+    .expect("key index out of range");
+    bits(&bm, n)
+}
+
+/// `multi_miller_loop` (`pairings.rs:808-857`) over (G1 point, prepared key) terms.
+pub fn multi_miller_loop_prepared(keys: &PreparedKeys, terms: &[(&G1Affine, u32)]) -> Result<MillerLoopResult, Bn254Error> {
+    let g1: Vec<u8> = terms.iter().flat_map(|t| t.0.to_uncompressed()).collect();
+    let idx: Vec<u32> = terms.iter().map(|t| t.1).collect();
+    let mut out = [0u8; 384];
+    with_ctx(|c| check(unsafe { ffi::blsbn254_multi_miller_loop_prepared(c, keys.0, idx.as_ptr(), g1.as_ptr(), terms.len(), out.as_mut_ptr()) }))?;
+    Ok(MillerLoopResult(Option::<Gt>::from(Gt::from_repr(&out)).expect("engine output is canonical").0))
+}
+
 // ---------------------------------------------------------------- N GPUs of one node
 
 /// All GPUs named in `BLSBN254_DEVICES` (comma-separated HIP ordinals, default "0"): one context and one host thread per
