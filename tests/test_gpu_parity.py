@@ -489,6 +489,28 @@ def test_chunked_entry_points(oracle, pyref, M, monkeypatch):
         e.close()
 
 
+def test_chunked_prepared_paths(oracle, M, monkeypatch):
+    """Chunked calls on the prepared-key paths (chunk forced to 2048): every chunk de-duplicates and prepares its own keys;
+    the explicit G2Prepared form walks the same key table chunk by chunk.  Same bitmap as the unchunked engine and the oracle."""
+    dst = M.DEFAULT_DST
+    n = 2048 * 2 + 900
+    pks, msgs, sigs, exp = _mixed_batch(oracle, n, dst, pool=5, seed=4242)
+    want = synth.bitmap_of(exp)
+    monkeypatch.setenv("BLSBN254_CHUNK_LANES", "2048")
+    e = M.Engine(0)
+    try:
+        p0, e0 = e.path_stats()
+        assert e.verify_batch(pks, msgs, sigs, dst) == want
+        assert e.path_stats() == (p0 + 2, e0 + 1)                  # two full chunks on the prepared path, the 900-tuple tail (< 1024) on the exact one
+        keys = sorted(set(pks[128 * i:128 * i + 128] for i in range(n)))
+        index = {k: j for j, k in enumerate(keys)}
+        prep = e.g2_prepare_batch(b"".join(keys), len(keys))
+        assert e.verify_batch_prepared(prep, [index[pks[128 * i:128 * i + 128]] for i in range(n)], msgs, sigs, dst) == want
+        prep.close()
+    finally:
+        e.close()
+
+
 def _rand_coeffs(seed, n, per):
     """n elements of `per` canonical 32-byte big-endian coefficients (top byte < 0x30 keeps every value below p); the first
     elements carry the edge values 0, 1, p - 1."""
