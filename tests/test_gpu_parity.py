@@ -666,6 +666,24 @@ def test_prepared_key_path_equals_exact_path(eng, oracle, M, n, pool):
     assert oracle.verify_batch(pks, msgs, sigs, dst, nthreads=16) == want       # ~3 s of CPU at n = 20000
 
 
+@pytest.mark.parametrize("pool,prepared", [(512, True), (513, False)])
+def test_prepared_path_threshold(eng, oracle, M, pool, prepared):
+    """the switch-over: a chunk takes the prepared path exactly when at most half of its public keys are distinct"""
+    dst = M.DEFAULT_DST
+    n = 1024
+    skb = b"".join(synth.sk_of(k).to_bytes(32, "big") for k in range(pool))
+    pkp = eng.sk_to_pk_batch(skb, pool)
+    msgs = [synth.msg_of(90000 + i) for i in range(n)]
+    idx = [i % pool for i in range(n)]
+    pks = b"".join(pkp[128 * k:128 * k + 128] for k in idx)
+    sigs = bytearray(eng.sign_batch(b"".join(skb[32 * k:32 * k + 32] for k in idx), msgs, dst))
+    sigs[64 * 7 + 63] ^= 1                                       # one bad signature
+    p0, e0 = eng.path_stats()
+    bm = eng.verify_batch(pks, msgs, bytes(sigs), dst)
+    assert eng.path_stats() == ((p0 + 1, e0) if prepared else (p0, e0 + 1))
+    assert bm == synth.bitmap_of([i != 7 for i in range(n)])
+
+
 def test_prepared_path_not_taken_for_distinct_keys(eng, oracle, M):
     """mostly distinct keys: the de-duplication finds more than n / 2 of them and the exact path runs"""
     dst = M.DEFAULT_DST
