@@ -206,7 +206,7 @@ void hs_miller_verify_only(const uint8_t* pk, const uint8_t* sig, const uint8_t*
 void hs_miller_verify_ws(const uint8_t* pk, const uint8_t* sig, const uint8_t* h64, uint8_t* ml_out, int* flags_out) {
   bool ok; G1A h = g1_decode(h64, ok);
   uint8_t flags;
-  static int32_t inv[72];
+  static int32_t inv[126];        // 72 limbs of invariants + 54 for the parked running point (-DBN_VERIFY_PARK_T, as the kernel is built)
   Fp12 f = lane_miller_verify_ws(pk, sig, h, BN_NEG_G2_LINE_TABLE, flags, Ws{inv, 1, 0, false});
   fp12_to_be(ml_out, f);
   *flags_out = flags;
