@@ -183,7 +183,7 @@ def run_rank(args):
                 if "k_" + dom in tj.get("kernels", {}):
                     traffic = tj["kernels"]["k_" + dom]["hbm_bytes_per_launch"]
                     traffic_note = ("PMC FETCH_SIZE/WRITE_SIZE of the same kernel at the same batch size (profiles/%s): "
-                                    "%.1f KB per tuple against ~0.6 KB algorithmic (sig 64 B, H 72 B, f out 432 B; line tables from cache)"
+                                    "%.1f KB per tuple against ~0.6 KB algorithmic (sig 64 B, H 108 B, f out 432 B; line tables from cache)"
                                     % (tname, traffic / n / 1024.0))
                     break
         if world == 1:

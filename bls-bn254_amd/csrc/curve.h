@@ -335,7 +335,8 @@ BN_FUNC G1A svdw_g1_finish(const Fp& u_in, const Fp& tv3) {       // tv3 = inv0(
 BN_FUNC G1A svdw_g1(const Fp& u) { return svdw_g1_finish(u, fp_inv(svdw_g1_den(u))); }
 // hash_to_curve for G1 (g1.rs:910-919): map two field elements, add, no cofactor.  One inversion serves both
 // maps (1/(d0 d1), then times d1 and d0); a zero denominator keeps the map's inv0(0) = 0.
-BN_FUNC G1A hash_to_g1_from_fields(const Fp& u0, const Fp& u1) {
+// the sum of the two mapped points in homogeneous coordinates (no final inversion)
+BN_FUNC G1P hash_to_g1_from_fields_proj(const Fp& u0, const Fp& u1) {
   BN_CTX;
   Fp d0 = svdw_g1_den(u0), d1 = svdw_g1_den(u1);
   bool z0 = fp_is_zero(d0), z1 = fp_is_zero(d1);
@@ -343,8 +344,9 @@ BN_FUNC G1A hash_to_g1_from_fields(const Fp& u0, const Fp& u1) {
   Fp inv = fp_inv(fp_mul(e0, e1));
   Fp i0 = fp_select(z0, fp_zero(), fp_mul(inv, e1)), i1 = fp_select(z1, fp_zero(), fp_mul(inv, e0));
   G1A q0 = svdw_g1_finish(u0, i0), q1 = svdw_g1_finish(u1, i1);
-  return g1_to_affine(proj_add(proj_from_affine(q0), proj_from_affine(q1)));
+  return proj_add(proj_from_affine(q0), proj_from_affine(q1));
 }
+BN_FUNC G1A hash_to_g1_from_fields(const Fp& u0, const Fp& u1) { return g1_to_affine(hash_to_g1_from_fields_proj(u0, u1)); }
 
 // Fp2 helpers for the G2 map
 BN_FUNC Fp2 fp2_pow(const Fp2& a, Exp256 e) {

@@ -9,11 +9,11 @@
 #include "kernels.h"
 using namespace bn;
 
-// sorted position s -> tuple perm[s] with key id kid[perm[s]].  f_ws / flags are in SORTED order.
+// sorted position s -> tuple perm[s] with key id kid[perm[s]].  f_ws / flags are in SORTED order.  h_ws: H(msg) homogeneous, 27 x h_stride limbs.
 // flags[s] = signature decodes, is not the identity, is on the curve, AND the key passed its checks (key_ok).
 BN_KERNEL k_miller_prepared(const uint32_t* perm, const uint32_t* kid, const uint8_t* sigs, const int32_t* h_ws, size_t h_stride,
                             const int32_t* table, const uint8_t* key_ok, size_t n, int32_t* f_ws, uint8_t* flags) {
-  __shared__ int32_t inv_lds[72 * 256];          // each lane touches only its own column: no barrier needed
+  __shared__ int32_t inv_lds[81 * 256];          // each lane touches only its own column: no barrier needed
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   const uint32_t i = perm[s], k = kid[i];
@@ -24,10 +24,10 @@ BN_KERNEL k_miller_prepared(const uint32_t* perm, const uint32_t* kid, const uin
   const Ws inv = {inv_lds, 256, threadIdx.x * 4u, false};
   const Ws hw = {const_cast<int32_t*>(h_ws), h_stride, i * 4u, true};
   const Fp xs = fp_norm(fp_select(sig_ok, sig.x, gp.x)), ys = fp_norm(fp_select(sig_ok, sig.y, gp.y));
-  const Fp xh = fp_load_mem(hw), yh = fp_load_mem(ws_at(hw, 9));
-  fp_store_mem(inv, xs); fp_store_mem(ws_at(inv, 9), ys); fp_store_mem(ws_at(inv, 18), xh); fp_store_mem(ws_at(inv, 27), yh);
-  fp_store_mem(ws_at(inv, 36), fp_mul(ys, yh)); fp_store_mem(ws_at(inv, 45), fp_mul(xs, xh));
-  fp_store_mem(ws_at(inv, 54), fp_mul(ys, xh)); fp_store_mem(ws_at(inv, 63), fp_mul(xs, yh));
+  const Fp X = fp_load_mem(hw), Y = fp_load_mem(ws_at(hw, 9)), Z = fp_load_mem(ws_at(hw, 18));       // H(msg) = (X : Y : Z), from k_hash_to_g1 mode 3
+  fp_store_mem(inv, X); fp_store_mem(ws_at(inv, 9), Y); fp_store_mem(ws_at(inv, 18), Z);
+  fp_store_mem(ws_at(inv, 27), fp_mul(xs, X)); fp_store_mem(ws_at(inv, 36), fp_mul(ys, Y)); fp_store_mem(ws_at(inv, 45), fp_mul(xs, Z));
+  fp_store_mem(ws_at(inv, 54), fp_mul(ys, Z)); fp_store_mem(ws_at(inv, 63), fp_mul(ys, X)); fp_store_mem(ws_at(inv, 72), fp_mul(xs, Y));
   BN_MEM_FENCE;
   const Ws kt = {const_cast<int32_t*>(table), 1, k * (uint32_t)(BN_NEG_G2_LINES * 162 * 4), true};
   fp12_store_limbs(Ws{f_ws, n, s * 4u, true}, miller_loop_prepared(inv, kt));

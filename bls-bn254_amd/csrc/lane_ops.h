@@ -31,6 +31,13 @@ BN_FUNC G1A lane_hash_to_g1(const uint8_t* msg, size_t msg_len, const uint8_t* d
   expand_message_xmd(okm, 96, msg, msg_len, dst, dst_len);
   return hash_to_g1_from_fields(fp_from_okm(okm), fp_from_okm(okm + 48));
 }
+// the same point in homogeneous coordinates (X : Y : Z), without the inversion of the affine form: the table-only Miller
+// loop evaluates its lines at (X, Y, Z) directly (the factor Z per line pair lies in Fp and dies in the final exponentiation)
+BN_FUNC G1P lane_hash_to_g1_proj(const uint8_t* msg, size_t msg_len, const uint8_t* dst, uint32_t dst_len) {
+  uint8_t okm[96];
+  expand_message_xmd(okm, 96, msg, msg_len, dst, dst_len);
+  return hash_to_g1_from_fields_proj(fp_from_okm(okm), fp_from_okm(okm + 48));
+}
 BN_FUNC G1A lane_encode_to_g1(const uint8_t* msg, size_t msg_len, const uint8_t* dst, uint32_t dst_len) {   // g1.rs:922-928
   uint8_t okm[48];
   expand_message_xmd(okm, 48, msg, msg_len, dst, dst_len);

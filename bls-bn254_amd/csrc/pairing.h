@@ -571,8 +571,9 @@ BN_FUNC void g2_prepare_lines(const G2A& q, const Ws& out) {
 //   la lb = (a0b0 ys yh + xi a4b4) + a3b3 xs xh v + (a3b4 xs + a4b3 xh) v^2 + [(a0b3 ys xh + a3b0 xs yh) + (a0b4 ys + a4b0 yh) v] w
 // The nine Fp2 products a_i b_j depend on the key only (k_g2_expand, 162 limbs per line: T0 = a0b0, T1 = xi a4b4, T2 = a3b3,
 // T3 = a3b4, T4 = a4b3, T5 = a0b3, T6 = a3b0, T7 = a0b4, T8 = a4b0); per tuple four products of coordinates are formed once.
-// A step then spends 2 scalings + 3 double products (2106 MADs) on the line pair instead of 4 scalings + 6 Fp2 products
-// (4212), and the 17-product sparse multiplication of f is unchanged.  Same field values, hence the same bitmap.
+// A step then spends 1 scaling + 4 double products (2268 MADs) on the line pair instead of 4 scalings + 6 Fp2 products
+// (4212), and the 17-product sparse multiplication of f is unchanged.  The loop's value differs from the textbook product of
+// the two Miller values only by powers of Z (an element of Fp), which the final exponentiation removes: same bitmap.
 BN_FUNC void line_pair_expand(const Line& a, const Line& b, const Ws& out) {
   BN_CTX;
   fp2_store_limbs(out, fp2_mul(a.c0, b.c0));
@@ -588,24 +589,27 @@ BN_FUNC void line_pair_expand(const Line& a, const Line& b, const Ws& out) {
 BN_INL Fp2 fp2_dot_fp(const Fp2& t, const Fp& s, const Fp2& u, const Fp& r) {      // t s + u r, one reduction per component
   return {fp_dot2(t.c0, s, u.c0, r), fp_dot2(t.c1, s, u.c1, r)};
 }
-// f * (la lb) from the expanded pair `e` (this step's 162 limbs) and the tuple's coordinates in `cw` (LDS, 9 limbs each:
-// xs, ys, xh, yh, ys yh, xs xh, ys xh, xs yh)
+// f * (la lb Z) from the expanded pair `e` (this step's 162 limbs) and the tuple's coordinates in `cw` (LDS, 9 limbs each):
+// the signature (xs, ys) affine, H(msg) = (X : Y : Z) homogeneous as the hash kernel leaves it (no inversion), and their products
+//   cw: 0 X, 1 Y, 2 Z, 3 xs X, 4 ys Y, 5 xs Z, 6 ys Z, 7 ys X, 8 xs Y
+// la lb Z = (T0 ys Y + T1 Z) + T2 xs X v + (T3 xs Z + T4 X) v^2 + [(T5 ys X + T6 xs Y) + (T7 ys Z + T8 Y) v] w
 BN_FUNC Fp12 ell_pair_expanded(const Fp12& f, const Ws& e, const Ws& cw) {
   BN_CTX;
-  Fp xs = fp_load_mem(cw), ys = fp_load_mem(ws_at(cw, 9)), xh = fp_load_mem(ws_at(cw, 18)), yh = fp_load_mem(ws_at(cw, 27));
-  Fp ysyh = fp_load_mem(ws_at(cw, 36)), xsxh = fp_load_mem(ws_at(cw, 45)), ysxh = fp_load_mem(ws_at(cw, 54)), xsyh = fp_load_mem(ws_at(cw, 63));
-  Fp6 l0 = {fp2_norm(fp2_add(fp2_mul_fp(fp2_load_limbs(e), ysyh), fp2_load_limbs(ws_at(e, 18)))),
-            fp2_mul_fp(fp2_load_limbs(ws_at(e, 36)), xsxh),
-            fp2_dot_fp(fp2_load_limbs(ws_at(e, 54)), xs, fp2_load_limbs(ws_at(e, 72)), xh)};
-  Fp2 l10 = fp2_dot_fp(fp2_load_limbs(ws_at(e, 90)), ysxh, fp2_load_limbs(ws_at(e, 108)), xsyh);
-  Fp2 l11 = fp2_dot_fp(fp2_load_limbs(ws_at(e, 126)), ys, fp2_load_limbs(ws_at(e, 144)), yh);
+  Fp X = fp_load_mem(cw), Y = fp_load_mem(ws_at(cw, 9)), Z = fp_load_mem(ws_at(cw, 18));
+  Fp xsX = fp_load_mem(ws_at(cw, 27)), ysY = fp_load_mem(ws_at(cw, 36)), xsZ = fp_load_mem(ws_at(cw, 45));
+  Fp ysZ = fp_load_mem(ws_at(cw, 54)), ysX = fp_load_mem(ws_at(cw, 63)), xsY = fp_load_mem(ws_at(cw, 72));
+  Fp6 l0 = {fp2_dot_fp(fp2_load_limbs(e), ysY, fp2_load_limbs(ws_at(e, 18)), Z),
+            fp2_mul_fp(fp2_load_limbs(ws_at(e, 36)), xsX),
+            fp2_dot_fp(fp2_load_limbs(ws_at(e, 54)), xsZ, fp2_load_limbs(ws_at(e, 72)), X)};
+  Fp2 l10 = fp2_dot_fp(fp2_load_limbs(ws_at(e, 90)), ysX, fp2_load_limbs(ws_at(e, 108)), xsY);
+  Fp2 l11 = fp2_dot_fp(fp2_load_limbs(ws_at(e, 126)), ysZ, fp2_load_limbs(ws_at(e, 144)), Y);
   Fp6 v0 = fp6_mul(f.c0, l0);
   Fp6 v1 = fp6_mul_by_01(f.c1, l10, l11);
   Fp6 dl = {fp2_norm(fp2_sub(l10, l0.c0)), fp2_norm(fp2_sub(l11, l0.c1)), fp2_norm(fp2_neg(l0.c2))};       // l1 - l0
   Fp6 w = fp6_mul(fp6_norm(fp6_sub(f.c0, f.c1)), dl);
   return {fp6_add_mul_v(v0, v1), fp6_norm(fp6_add(fp6_add(w, v0), v1))};
 }
-// inv (LDS, 72 limbs): xs, ys, xh, yh and their four products; ktab: this lane's key, 88 x 162 limbs
+// inv (LDS, 81 limbs): the nine coordinate values listed above; ktab: this lane's key, 88 x 162 limbs
 BN_FUNC Fp12 miller_loop_prepared(const Ws& inv, const Ws& ktab_in) {
   Fp12 f = fp12_one();
   Ws p = inv, kt = ktab_in;

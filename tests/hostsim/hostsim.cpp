@@ -71,21 +71,28 @@ void hs_miller2(const uint8_t* ha, const uint8_t* qa, const uint8_t* hb, const u
   g2_prepare_lines(Qa, Ws{ta, 1, 0, false}); g2_prepare_lines(Qb, Ws{tb, 1, 0, false});
   fp12_to_be(out2, miller_loop_2prepared(whh, Ws{ta, 1, 0, false}, Ws{tb, 1, 0, false}, true, live_b != 0));
 }
-// ML(sig, -G2gen) * ML(H, pk) by the pair tables of the prepared-key verify path
-void hs_miller_prepared(const uint8_t* sig, const uint8_t* h, const uint8_t* pk, uint8_t* out) {
+// ML(sig, -G2gen) * ML(H, pk) by the pair tables of the prepared-key verify path, H given homogeneously as (x z : y z : z)
+// with z = the Montgomery form of z_small; the loop's value is the textbook Miller product times z^88, so out = the value
+// after the final exponentiation (which removes the Fp factor), and z_small = 1 gives the textbook Miller value in ml_out
+void hs_miller_prepared(const uint8_t* sig, const uint8_t* h, const uint8_t* pk, int z_small, uint8_t* ml_out, uint8_t* gt_out) {
   bool ok;
   G1A S = g1_decode(sig, ok), H = g1_decode(h, ok);
   G2A Q = g2_decode(pk, ok);
-  static int32_t raw[88 * 54], exp_[88 * 162], inv[72];
+  static int32_t raw[88 * 54], exp_[88 * 162], inv[81];
   g2_prepare_lines(Q, Ws{raw, 1, 0, false});
   for (int t = 0; t < 88; ++t)
     line_pair_expand(line_from_table(BN_NEG_G2_LINE_TABLE[t]), line_load_limbs(Ws{raw + 54 * t, 1, 0, false}), Ws{exp_ + 162 * t, 1, 0, false});
+  Fp z = fp_one();
+  for (int k = 1; k < z_small; ++k) z = fp_norm(fp_add(z, fp_one()));
+  z = fp_canon(z);
   const Ws w = {inv, 1, 0, false};
-  Fp xs = fp_norm(S.x), ys = fp_norm(S.y), xh = fp_norm(H.x), yh = fp_norm(H.y);
-  fp_store_mem(w, xs); fp_store_mem(ws_at(w, 9), ys); fp_store_mem(ws_at(w, 18), xh); fp_store_mem(ws_at(w, 27), yh);
-  fp_store_mem(ws_at(w, 36), fp_mul(ys, yh)); fp_store_mem(ws_at(w, 45), fp_mul(xs, xh));
-  fp_store_mem(ws_at(w, 54), fp_mul(ys, xh)); fp_store_mem(ws_at(w, 63), fp_mul(xs, yh));
-  fp12_to_be(out, miller_loop_prepared(w, Ws{exp_, 1, 0, false}));
+  Fp xs = fp_norm(S.x), ys = fp_norm(S.y), X = fp_mul(fp_norm(H.x), z), Y = fp_mul(fp_norm(H.y), z), Z = z;
+  fp_store_mem(w, X); fp_store_mem(ws_at(w, 9), Y); fp_store_mem(ws_at(w, 18), Z);
+  fp_store_mem(ws_at(w, 27), fp_mul(xs, X)); fp_store_mem(ws_at(w, 36), fp_mul(ys, Y)); fp_store_mem(ws_at(w, 45), fp_mul(xs, Z));
+  fp_store_mem(ws_at(w, 54), fp_mul(ys, Z)); fp_store_mem(ws_at(w, 63), fp_mul(ys, X)); fp_store_mem(ws_at(w, 72), fp_mul(xs, Y));
+  Fp12 f = miller_loop_prepared(w, Ws{exp_, 1, 0, false});
+  fp12_to_be(ml_out, f);
+  fp12_to_be(gt_out, final_exponentiation(f));
 }
 int hs_final_exp(const uint8_t* in, uint8_t* out) {
   bool ok;

@@ -209,5 +209,8 @@ def test_parked_and_prepared_miller_loops(hs, oracle, pyref):
         hs.hs_miller2(ha, qa, hb, qb, 0, o1, o2)                 # second pair is padding: contributes exactly 1
         want = oracle.multi_miller_loop(ha, qa, 1)
         assert o1.raw == want and o2.raw == want
-        hs.hs_miller_prepared(sig, ha, qa, o1)
-        assert o1.raw == oracle.multi_miller_loop(sig + ha, neg_g2 + qa, 2)
+        want = oracle.multi_miller_loop(sig + ha, neg_g2 + qa, 2)
+        hs.hs_miller_prepared(sig, ha, qa, 1, o1, o2)            # H = (x : y : 1): the textbook Miller value itself
+        assert o1.raw == want and o2.raw == oracle.final_exponentiation(want, 1)
+        hs.hs_miller_prepared(sig, ha, qa, 5, o1, o2)            # H = (5x : 5y : 5): differs by 5^88 in Fp, gone after the final exponentiation
+        assert o1.raw != want and o2.raw == oracle.final_exponentiation(want, 1)
