@@ -39,6 +39,13 @@ struct blsbn254_ctx {
   DevBuf in_a, in_b, in_c, in_off, dst, h_ws, f_ws, f_ws2, flags, sub_ok, status, bitmap, out, scalars, misc;
   DevBuf fe[6];          // final-exponentiation phase buffers (x, a, b, c, b2, d), 108 x n limbs each
   DevBuf rlc_a2, rlc_a, rlc_b, rlc_elig, rlc_f2, rlc_bytes, rlc_neg, rlc_ok, rlc_idx, rlc_cpk, rlc_csig, rlc_ch, rlc_csub, rlc_cbm;   // RLC batch verification
+  // RLC over repeated keys (k_rlc2.hip): weighted points, chunk descriptions, virtual tuples, fallback list
+  DevBuf r2_seed, r2_a, r2_b, r2_sigok, r2_tchunk, r2_ccnt, r2_cbase, r2_ckid, r2_cstart, r2_clen, r2_csig, r2_ch, r2_cstate, r2_iota, r2_cisone,
+         r2_need, r2_bcnt, r2_bbase, r2_list, r2_valid;
+  size_t rlc_group = 16;             // tuples per chunk (BLSBN254_RLC_GROUP / blsbn254_set_rlc_group)
+  bool rlc_group_auto = true;        // no explicit setting: 16, raised (to at most 32) when that saves a whole round of waves
+  size_t lanes_per_round = 65536;    // CUs x 256: the lanes resident at one wave per SIMD (the big kernels' occupancy)
+  uint64_t stat_rlc[4] = {0, 0, 0, 0};   // tuples on the chunked path, chunks checked, tuples sent to the exact fallback, tuples on the exact path (distinct keys)
   DevBuf status_all;     // per-element decode status of a chunked call, all chunks
   // prepared-key verify path (k_keyprep.hip, k_miller_prep.hip)
   DevBuf kd_slots, kd_rep, kd_kid, kd_keys, kd_hist, kd_cursor, kd_perm, kd_cnt, prep_table, prep_raw, prep_ok, prep_isone, prep_valid;
@@ -134,6 +141,8 @@ int blsbn254_ctx_create(int device, blsbn254_ctx** out) {
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(c->stream); delete c; return BLSBN254_E_HIP; }
   if (getrandom(&c->kd_seed, sizeof c->kd_seed, 0) != (ssize_t)sizeof c->kd_seed) c->kd_seed = 0x5bd1e995u;
   if (const char* e = std::getenv("BLSBN254_AUTO_PREPARE")) c->auto_prepare = std::atoi(e) != 0;
+  if (const char* e = std::getenv("BLSBN254_RLC_GROUP")) { long v = std::atol(e); if (v >= 2 && v <= 4096) { c->rlc_group = (size_t)v; c->rlc_group_auto = false; } }
+  c->lanes_per_round = (size_t)prop.multiProcessorCount * 256;
   *out = c;
   return 0;
 }
@@ -152,6 +161,9 @@ void blsbn254_ctx_destroy(blsbn254_ctx* c) {
   { DevBuf* kb[] = {&c->kd_slots, &c->kd_rep, &c->kd_kid, &c->kd_keys, &c->kd_hist, &c->kd_cursor, &c->kd_perm, &c->kd_cnt, &c->prep_table, &c->prep_raw, &c->prep_ok,
                     &c->prep_isone, &c->prep_valid};
     for (DevBuf* b : kb) b->release(); }
+  { DevBuf* rb[] = {&c->r2_seed, &c->r2_a, &c->r2_b, &c->r2_sigok, &c->r2_tchunk, &c->r2_ccnt, &c->r2_cbase, &c->r2_ckid, &c->r2_cstart, &c->r2_clen, &c->r2_csig,
+                    &c->r2_ch, &c->r2_cstate, &c->r2_iota, &c->r2_cisone, &c->r2_need, &c->r2_bcnt, &c->r2_bbase, &c->r2_list, &c->r2_valid};
+    for (DevBuf* b : rb) b->release(); }
   (void)hipStreamSynchronize(c->stream2);
   (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join);
   (void)hipStreamDestroy(c->stream2);
@@ -549,6 +561,17 @@ static int dedup_keys(blsbn254_ctx* c, const uint8_t* d_pks, size_t n, size_t* u
   *u_out = u;
   return 0;
 }
+// the exact per-tuple path: every tuple validates its own key and runs the two-pair Miller loop with a variable-Q pair
+static int verify_exact_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
+                            const uint8_t* d_sigs, size_t n, uint32_t dl, uint8_t* d_bitmap) {
+  ++c->stat_exact_chunks;
+  HIPCHK(c, c->h_ws.reserve(n * 18 * 4)); HIPCHK(c, c->f_ws.reserve(n * 108 * 4));
+  HIPCHK(c, c->flags.reserve(n)); HIPCHK(c, c->sub_ok.reserve(n));
+  LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, d_msgs, d_off, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, n, (uint8_t*)nullptr, 0);
+  LAUNCH(c, "g2_check", k_g2_check, n, d_pks, n, (uint8_t*)c->sub_ok.p, (uint8_t*)nullptr);
+  LAUNCH(c, "miller_verify", k_miller_verify, n, d_pks, d_sigs, (const int32_t*)c->h_ws.p, n, (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
+  return run_final_exp(c, (int32_t*)c->f_ws.p, n, n, 0, (const uint8_t*)c->flags.p, (const uint8_t*)c->sub_ok.p, d_bitmap, nullptr, nullptr);
+}
 // Workspace is ~7.4 KB per tuple (H, f, six final-exponentiation phase buffers, ten chain slots); batches
 // larger than ctx->chunk (4 Mi) tuples are processed chunk by chunk so that any n fits the 288 GB of HBM.
 static int verify_chunk_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
@@ -571,13 +594,7 @@ static int verify_chunk_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t
                                  d_msgs, d_off, d_sigs, n, dl, d_bitmap, true);
     }
   }
-  ++c->stat_exact_chunks;
-  HIPCHK(c, c->h_ws.reserve(n * 18 * 4)); HIPCHK(c, c->f_ws.reserve(n * 108 * 4));
-  HIPCHK(c, c->flags.reserve(n)); HIPCHK(c, c->sub_ok.reserve(n));
-  LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, d_msgs, d_off, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, n, (uint8_t*)nullptr, 0);
-  LAUNCH(c, "g2_check", k_g2_check, n, d_pks, n, (uint8_t*)c->sub_ok.p, (uint8_t*)nullptr);
-  LAUNCH(c, "miller_verify", k_miller_verify, n, d_pks, d_sigs, (const int32_t*)c->h_ws.p, n, (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
-  return run_final_exp(c, (int32_t*)c->f_ws.p, n, n, 0, (const uint8_t*)c->flags.p, (const uint8_t*)c->sub_ok.p, d_bitmap, nullptr, nullptr);
+  return verify_exact_dev(c, d_pks, d_msgs, d_off, d_sigs, n, dl, d_bitmap);
 }
 int blsbn254_verify_batch_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
                               const uint8_t* d_sigs, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* d_bitmap) {
@@ -753,37 +770,196 @@ int blsbn254_path_stats(blsbn254_ctx* c, uint64_t out[2]) {
 }
 int blsbn254_set_auto_prepare(blsbn254_ctx* c, int on) { if (!c) return BLSBN254_E_ARG; c->auto_prepare = on != 0; return 0; }
 
+// ---------------- random-linear-combination batch verification over repeated keys (k_rlc2.hip)
+static int draw_seed(blsbn254_ctx* c, uint8_t out[32]) {
+  size_t got = 0;
+  while (got < 32) {
+    ssize_t k = getrandom(out + got, 32 - got, 0);
+    if (k <= 0) { c->last_error = "getrandom failed"; return BLSBN254_E_HIP; }
+    got += (size_t)k;
+  }
+  return 0;
+}
+// One table-only Miller loop + final exponentiation over `cnt` (virtual or real) tuples: is_one bytes to d_isone, flags in ctx->flags.
+static int prepared_round(blsbn254_ctx* c, const uint32_t* perm, const uint32_t* kid, const uint8_t* sigs, const int32_t* h_ws, size_t h_stride,
+                          size_t cnt, uint8_t* d_isone) {
+  HIPCHK(c, c->f_ws.reserve(cnt * 108 * 4)); HIPCHK(c, c->flags.reserve(cnt));
+  LAUNCH(c, "miller_prepared", k_miller_prepared, cnt, perm, kid, sigs, h_ws, h_stride, (const int32_t*)c->prep_table.p, (const uint8_t*)c->prep_ok.p, cnt,
+         (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
+  return run_final_exp(c, (int32_t*)c->f_ws.p, cnt, cnt, 4, nullptr, nullptr, nullptr, d_isone, nullptr);
+}
+// n <= ctx->chunk tuples, everything device-resident; d_seed = 32 bytes in device memory.  *took = 0 when the keys do not repeat
+// (nothing was done: the caller takes another path).
+static int rlc2_chunk_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs, size_t n,
+                          uint32_t dl, const uint8_t* d_seed, uint8_t* d_bitmap, bool* took) {
+  *took = false;
+  if (n < 2) return 0;
+  size_t u = 0;
+  int rc = dedup_keys(c, d_pks, n, &u);
+  if (rc) return rc;
+  if (!(u * 2 <= n && u <= PREP_MAX_KEYS)) return 0;
+  *took = true;
+  // Chunk size.  The chunk round runs one wave per SIMD, i.e. lanes_per_round virtual tuples at a time, and a launch that is a
+  // few chunks over a multiple of that pays a whole extra round: unless the caller fixed G, take the next G (at most 2 G)
+  // whose chunk-count bound n / G + u needs a round less.
+  size_t G = c->rlc_group;
+  if (c->rlc_group_auto) {
+    const size_t R = c->lanes_per_round;
+    const size_t r0 = (n / G + u + R - 1) / R;
+    for (size_t g = G + 1; r0 > 1 && g <= 2 * G; ++g)
+      if ((n / g + u + R - 1) / R < r0) { G = g; break; }
+  }
+  const size_t nblk = (n + 255) / 256;
+  const uint32_t G32 = (uint32_t)G, n32 = (uint32_t)n, u32 = (uint32_t)u;
+  HIPCHK(c, c->prep_table.reserve(u * PREP_KEY_LIMBS * 4)); HIPCHK(c, c->prep_ok.reserve(u));
+  rc = prepare_keys_async(c, d_pks, (const uint32_t*)c->kd_keys.p, u, (int32_t*)c->prep_table.p, (uint8_t*)c->prep_ok.p);
+  if (rc) return rc;
+  HIPCHK(c, c->h_ws.reserve(n * 27 * 4)); HIPCHK(c, c->kd_cursor.reserve(4 * (u + 1))); HIPCHK(c, c->kd_perm.reserve(4 * n));
+  HIPCHK(c, c->r2_a.reserve(n * 27 * 4)); HIPCHK(c, c->r2_b.reserve(n * 27 * 4)); HIPCHK(c, c->r2_sigok.reserve(n)); HIPCHK(c, c->r2_tchunk.reserve(4 * n));
+  HIPCHK(c, c->r2_ccnt.reserve(4 * (u + 2))); HIPCHK(c, c->r2_cbase.reserve(4 * (u + 2)));
+  HIPCHK(c, c->r2_need.reserve(n)); HIPCHK(c, c->r2_bcnt.reserve(4 * (nblk + 2))); HIPCHK(c, c->r2_bbase.reserve(4 * (nblk + 2)));
+  HIPCHK(c, c->r2_list.reserve(4 * n)); HIPCHK(c, c->r2_valid.reserve(n));
+  uint32_t *hist = (uint32_t*)c->kd_hist.p, *cursor = (uint32_t*)c->kd_cursor.p, *perm = (uint32_t*)c->kd_perm.p, *kid = (uint32_t*)c->kd_kid.p;
+  uint32_t *ccnt = (uint32_t*)c->r2_ccnt.p, *cbase = (uint32_t*)c->r2_cbase.p;
+  // key ids, key-sorted order, chunk numbering
+  HIPCHK(c, hipMemsetAsync(hist, 0, 4 * u, c->stream));
+  LAUNCH(c, "kd_propagate", k_kd_propagate, n, (const uint32_t*)c->kd_rep.p, n32, u32, kid, hist);
+  { ProfScope ps_(c, "kd_scan"); hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)hist, u32, cursor); }
+  HIPCHK(c, hipGetLastError());
+  LAUNCH(c, "kd_scatter", k_kd_scatter, n, (const uint32_t*)kid, n32, u32, cursor, perm);          // cursor[k] is now the END of run k
+  LAUNCH(c, "rlc2_counts", k_rlc2_chunk_counts, u + 1, (const uint32_t*)hist, u32, G32, ccnt);
+  { ProfScope ps_(c, "kd_scan"); hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)ccnt, u32 + 1, cbase); }
+  HIPCHK(c, hipGetLastError());
+  uint32_t m32 = 0;
+  HIPCHK(c, hipMemcpyAsync(&m32, cbase + u, 4, hipMemcpyDeviceToHost, c->stream));
+  // the hash points and the weighted points r_i sig_i, r_i H_i (the host learns the chunk count while these run)
+  LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, d_msgs, d_off, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, n, (uint8_t*)nullptr, 3);
+  LAUNCH(c, "rlc2_prep", k_rlc2_prep, n, (const uint32_t*)perm, d_pks, d_sigs, (const int32_t*)c->h_ws.p, n, d_seed, (int32_t*)c->r2_a.p, (int32_t*)c->r2_b.p,
+         (uint8_t*)c->r2_sigok.p);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t m = m32;
+  if (m == 0 || m > n) { c->last_error = "internal: chunk count out of range"; return BLSBN254_E_HIP; }
+  HIPCHK(c, c->r2_ckid.reserve(4 * m)); HIPCHK(c, c->r2_cstart.reserve(4 * m)); HIPCHK(c, c->r2_clen.reserve(4 * m)); HIPCHK(c, c->r2_csig.reserve(64 * m));
+  HIPCHK(c, c->r2_ch.reserve(27 * 4 * m)); HIPCHK(c, c->r2_cstate.reserve(m)); HIPCHK(c, c->r2_iota.reserve(4 * m)); HIPCHK(c, c->r2_cisone.reserve(m));
+  LAUNCH(c, "rlc2_mark", k_rlc2_mark, n, (const uint32_t*)perm, (const uint32_t*)kid, (const uint32_t*)hist, (const uint32_t*)cursor, (const uint32_t*)cbase, n32, G32,
+         (uint32_t*)c->r2_tchunk.p, (uint32_t*)c->r2_ckid.p, (uint32_t*)c->r2_cstart.p, (uint32_t*)c->r2_clen.p);
+  LAUNCH(c, "rlc2_sum", k_rlc2_sum, m, (const int32_t*)c->r2_a.p, (const int32_t*)c->r2_b.p, n, (const uint8_t*)c->r2_sigok.p, (const uint32_t*)c->r2_cstart.p,
+         (const uint32_t*)c->r2_clen.p, m, (uint8_t*)c->r2_csig.p, (int32_t*)c->r2_ch.p, (uint8_t*)c->r2_cstate.p);
+  LAUNCH(c, "iota", k_iota_u32, m, (uint32_t*)c->r2_iota.p, (uint32_t)m);
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));                      // the key tables are ready
+  // the chunk round: every chunk is one virtual tuple on the prepared-key verify path
+  rc = prepared_round(c, (const uint32_t*)c->r2_iota.p, (const uint32_t*)c->r2_ckid.p, (const uint8_t*)c->r2_csig.p, (const int32_t*)c->r2_ch.p, m, m, (uint8_t*)c->r2_cisone.p);
+  if (rc) return rc;
+  LAUNCH(c, "rlc2_resolve", k_rlc2_resolve, n, (const uint32_t*)perm, (const uint32_t*)kid, (const uint32_t*)c->r2_tchunk.p, (const uint8_t*)c->r2_sigok.p,
+         (const uint8_t*)c->prep_ok.p, (const uint8_t*)c->r2_cstate.p, (const uint8_t*)c->r2_cisone.p, (const uint8_t*)c->flags.p, n32, (uint8_t*)c->r2_valid.p,
+         (uint8_t*)c->r2_need.p, (uint32_t*)c->r2_bcnt.p);
+  { ProfScope ps_(c, "kd_scan"); hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)c->r2_bcnt.p, (uint32_t)nblk + 1, (uint32_t*)c->r2_bbase.p); }
+  HIPCHK(c, hipGetLastError());
+  uint32_t m2 = 0;
+  HIPCHK(c, hipMemcpyAsync(&m2, (uint32_t*)c->r2_bbase.p + nblk, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (m2 > n) { c->last_error = "internal: fallback count out of range"; return BLSBN254_E_HIP; }
+  c->stat_rlc[0] += n; c->stat_rlc[1] += m; c->stat_rlc[2] += m2;
+  if (m2) {                                                                     // eligible tuples of failed chunks: the exact prepared-key path
+    HIPCHK(c, c->prep_isone.reserve(m2));
+    LAUNCH(c, "rlc2_compact", k_rlc2_compact, n, (const uint8_t*)c->r2_need.p, (const uint32_t*)perm, n32, (const uint32_t*)c->r2_bbase.p, (uint32_t*)c->r2_list.p);
+    rc = prepared_round(c, (const uint32_t*)c->r2_list.p, (const uint32_t*)kid, d_sigs, (const int32_t*)c->h_ws.p, n, m2, (uint8_t*)c->prep_isone.p);
+    if (rc) return rc;
+    LAUNCH(c, "prep_unsort", k_prep_unsort, m2, (const uint8_t*)c->prep_isone.p, (const uint8_t*)c->flags.p, (const uint32_t*)c->r2_list.p, m2, (uint8_t*)c->r2_valid.p);
+  }
+  LAUNCH(c, "pack_bitmap", k_pack_bitmap, n, (const uint8_t*)c->r2_valid.p, n, d_bitmap);
+  return 0;
+}
+static int stage_seed(blsbn254_ctx* c, const uint8_t* seed) {
+  uint8_t own[32];
+  if (!seed) {                                        // the normal case: 32 bytes from the OS, drawn now -- after the batch is fixed
+    int rc = draw_seed(c, own);
+    if (rc) return rc;
+    seed = own;
+  }
+  HIPCHK(c, c->r2_seed.reserve(32));
+  HIPCHK(c, hipMemcpyAsync(c->r2_seed.p, seed, 32, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));         // `own` is on the stack
+  return 0;
+}
+int blsbn254_verify_batch_rlc_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs, size_t n,
+                                  const uint8_t* dst, size_t dst_len, const uint8_t seed[32], uint8_t* d_bitmap) {
+  if (!c || (n && (!d_pks || !d_off || !d_sigs || !d_bitmap)) || (dst_len && !dst)) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
+  if (rc) return rc;
+  rc = stage_seed(c, seed);
+  if (rc) return rc;
+  for (size_t lo = 0; lo < n; lo += c->chunk) {        // chunk starts are multiples of 8: bitmap bytes do not straddle
+    size_t m = n - lo < c->chunk ? n - lo : c->chunk;
+    bool took = false;
+    rc = rlc2_chunk_dev(c, d_pks + 128 * lo, d_msgs, d_off + lo, d_sigs + 64 * lo, m, dl, (const uint8_t*)c->r2_seed.p, d_bitmap + lo / 8, &took);
+    if (rc) return rc;
+    if (!took) {                                       // keys do not repeat: nothing to share per key, the exact per-tuple path
+      c->stat_rlc[3] += m;
+      rc = verify_exact_dev(c, d_pks + 128 * lo, d_msgs, d_off + lo, d_sigs + 64 * lo, m, dl, d_bitmap + lo / 8);
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}
+int blsbn254_set_rlc_group(blsbn254_ctx* c, size_t group) {
+  if (!c || group == 1 || group > 4096) return BLSBN254_E_ARG;
+  c->rlc_group = group ? group : 16;
+  c->rlc_group_auto = group == 0;
+  return 0;
+}
+int blsbn254_rlc_stats(blsbn254_ctx* c, uint64_t out[4]) {
+  if (!c || !out) return BLSBN254_E_ARG;
+  for (int k = 0; k < 4; ++k) out[k] = c->stat_rlc[k];
+  return 0;
+}
+
 // ---------------- random-linear-combination batch verification
-static const size_t RLC_GROUP = 16;      // tuples per shared final exponentiation (power of two)
+static const size_t RLC_GROUP = 16;      // distinct-key variant: tuples per shared final exponentiation (power of two)
 int blsbn254_verify_batch_rlc(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs,
                               size_t n, const uint8_t* dst, size_t dst_len, const uint8_t seed[32], uint8_t* bm) {
   if (!c || !off || (n && (!pks || !sigs || !bm)) || (dst_len && !dst)) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  CHECK_LANES(c, n);
-  uint8_t own_seed[32];
-  if (!seed) {                                        // the normal case: 32 bytes from the OS, drawn now -- after the batch is fixed
-    size_t got = 0;
-    while (got < sizeof own_seed) {
-      ssize_t k = getrandom(own_seed + got, sizeof own_seed - got, 0);
-      if (k <= 0) { c->last_error = "getrandom failed"; return BLSBN254_E_HIP; }
-      got += (size_t)k;
-    }
-    seed = own_seed;
-  }
   HIPCHK(c, hipSetDevice(c->device));
   uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
   if (rc) return rc;
   rc = stage_msgs(c, msgs, off, n);
   if (rc) return rc;
-  const size_t G = RLC_GROUP, n_pad = (n + G - 1) / G * G, ng = n_pad / G, nb = (n + 7) / 8;
-  HIPCHK(c, c->in_a.reserve(128 * n)); HIPCHK(c, c->in_b.reserve(64 * n)); HIPCHK(c, c->misc.reserve(64));
+  const size_t nb = (n + 7) / 8;
+  HIPCHK(c, c->in_a.reserve(128 * n)); HIPCHK(c, c->in_b.reserve(64 * n)); HIPCHK(c, c->bitmap.reserve(nb + 8));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->in_b.p, sigs, 64 * n, hipMemcpyHostToDevice, c->stream));
+  rc = stage_seed(c, seed);
+  if (rc) return rc;
+  // Repeated keys: per-key chunks as virtual tuples on the prepared-key path (k_rlc2.hip).  Batches beyond one launch chunk
+  // go chunk by chunk through the device entry point (which takes the exact path for a chunk of distinct keys).
+  bool took = false;
+  if (n <= c->chunk) {
+    rc = rlc2_chunk_dev(c, (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, (const uint8_t*)c->in_b.p, n, dl,
+                        (const uint8_t*)c->r2_seed.p, (uint8_t*)c->bitmap.p, &took);
+    if (rc) return rc;
+  } else {
+    rc = blsbn254_verify_batch_rlc_dev(c, (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, (const uint8_t*)c->in_b.p, n,
+                                       dst, dst_len, seed, (uint8_t*)c->bitmap.p);
+    if (rc) return rc;
+    took = true;
+  }
+  if (took) {
+    HIPCHK(c, hipMemcpyAsync(bm, c->bitmap.p, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+  }
+  // Distinct keys: groups of RLC_GROUP tuples in the caller's order share the signature-side Miller loop and the final exponentiation.
+  c->stat_rlc[3] += n;
+  const size_t G = RLC_GROUP, n_pad = (n + G - 1) / G * G, ng = n_pad / G;
+  HIPCHK(c, c->misc.reserve(64));
   HIPCHK(c, c->h_ws.reserve(n * 18 * 4)); HIPCHK(c, c->sub_ok.reserve(n)); HIPCHK(c, c->flags.reserve(n_pad));
   HIPCHK(c, c->rlc_a.reserve(n_pad * 27 * 4)); HIPCHK(c, c->rlc_b.reserve(n_pad * 18 * 4)); HIPCHK(c, c->rlc_elig.reserve(n_pad));
   HIPCHK(c, c->f_ws.reserve(n_pad * 108 * 4)); HIPCHK(c, c->rlc_f2.reserve(ng * 108 * 4)); HIPCHK(c, c->rlc_bytes.reserve(ng * 64));
   HIPCHK(c, c->rlc_neg.reserve(ng * 128)); HIPCHK(c, c->rlc_ok.reserve(ng)); HIPCHK(c, c->status.reserve(ng + 8));
-  HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * n, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->in_b.p, sigs, 64 * n, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->misc.p, seed, 32, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->misc.p, c->r2_seed.p, 32, hipMemcpyDeviceToDevice, c->stream));
   { std::vector<uint8_t> neg(ng * 128);
     for (size_t g = 0; g < ng; ++g) std::memcpy(neg.data() + 128 * g, NEG_G2_BYTES, 128);
     HIPCHK(c, hipMemcpyAsync(c->rlc_neg.p, neg.data(), ng * 128, hipMemcpyHostToDevice, c->stream));

@@ -63,6 +63,18 @@ BN_KERNEL k_fp12_mul_elem(int32_t* a, size_t sa, const int32_t* b, size_t sb, si
 BN_KERNEL k_g1p_to_bytes(const int32_t* ws, size_t stride, size_t m, uint8_t* out);
 BN_KERNEL k_rlc_gather(const uint32_t* idx, size_t m, const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n,
                        const uint8_t* sub_ok, uint8_t* c_pks, uint8_t* c_sigs, int32_t* c_h, uint8_t* c_sub);
+BN_KERNEL k_rlc2_prep(const uint32_t* perm, const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n, const uint8_t* seed,
+                      int32_t* a_ws, int32_t* b_ws, uint8_t* sig_ok);
+__global__ void k_rlc2_chunk_counts(const uint32_t* hist, uint32_t u, uint32_t G, uint32_t* cnt);
+__global__ void k_rlc2_mark(const uint32_t* perm, const uint32_t* kid, const uint32_t* hist, const uint32_t* run_end, const uint32_t* chunk_base,
+                            uint32_t n, uint32_t G, uint32_t* tuple_chunk, uint32_t* chunk_kid, uint32_t* chunk_start, uint32_t* chunk_len);
+BN_KERNEL k_rlc2_sum(const int32_t* a_ws, const int32_t* b_ws, size_t n, const uint8_t* sig_ok, const uint32_t* chunk_start, const uint32_t* chunk_len,
+                     size_t m, uint8_t* c_sig, int32_t* c_h, uint8_t* c_state);
+__global__ void k_iota_u32(uint32_t* out, uint32_t n);
+__global__ void __launch_bounds__(256) k_rlc2_resolve(const uint32_t* perm, const uint32_t* kid, const uint32_t* tuple_chunk, const uint8_t* sig_ok,
+                                                      const uint8_t* key_ok, const uint8_t* c_state, const uint8_t* c_isone, const uint8_t* c_flags,
+                                                      uint32_t n, uint8_t* valid, uint8_t* need, uint32_t* block_cnt);
+__global__ void __launch_bounds__(256) k_rlc2_compact(const uint8_t* need, const uint32_t* perm, uint32_t n, const uint32_t* block_base, uint32_t* list);
 BN_KERNEL k_field_op(int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status);
 BN_KERNEL k_gt_pow(const uint8_t* gt, const uint8_t* scalars, size_t n, uint8_t* out, uint8_t* status);
 BN_KERNEL k_fr_decode(const uint8_t* ids, size_t t, int32_t* x_ws, uint8_t* status);

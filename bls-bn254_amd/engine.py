@@ -262,6 +262,16 @@ class Engine:
                                                       ctypes.c_size_t(len(dst)), psd, po))
         return o[:(n + 7) // 8].tobytes()
 
+    def set_rlc_group(self, group):
+        """tuples per chunk of the repeated-key RLC path; 0 = automatic (16, raised when that saves a round of waves)"""
+        self._chk(self._lib.blsbn254_set_rlc_group(self._ctx, ctypes.c_size_t(group)))
+
+    def rlc_stats(self):
+        """dict: tuples verified through chunks, chunks checked, tuples re-verified exactly, tuples of distinct-key batches"""
+        o = (ctypes.c_uint64 * 4)()
+        self._chk(self._lib.blsbn254_rlc_stats(self._ctx, o))
+        return {"chunked_tuples": int(o[0]), "chunks": int(o[1]), "fallback_tuples": int(o[2]), "distinct_key_tuples": int(o[3])}
+
     def aggregate_verify(self, pks, msgs, agg_sig, dst=DEFAULT_DST):
         n = len(msgs)
         data, off = pack_messages(msgs)
@@ -399,6 +409,16 @@ class Engine:
         self._chk(self._lib.blsbn254_verify_batch_dev(self._ctx, ctypes.c_void_p(d_pks), ctypes.c_void_p(d_msgs), ctypes.c_void_p(d_off),
                                                       ctypes.c_void_p(d_sigs), ctypes.c_size_t(n), pd, ctypes.c_size_t(len(dst)),
                                                       ctypes.c_void_p(d_bitmap)))
+
+    def verify_batch_rlc_dev(self, d_pks, d_msgs, d_off, d_sigs, n, d_bitmap, dst=DEFAULT_DST, seed=None):
+        d, pd = _inbuf(dst)
+        if seed is None:
+            sd, psd = None, ctypes.cast(None, _u8p)
+        else:
+            sd, psd = _inbuf(seed, 32)
+        self._chk(self._lib.blsbn254_verify_batch_rlc_dev(self._ctx, ctypes.c_void_p(d_pks), ctypes.c_void_p(d_msgs), ctypes.c_void_p(d_off),
+                                                          ctypes.c_void_p(d_sigs), ctypes.c_size_t(n), pd, ctypes.c_size_t(len(dst)), psd,
+                                                          ctypes.c_void_p(d_bitmap)))
 
     def pairing_batch_dev(self, d_g1, d_g2, n, d_gt, d_status=0):
         self._chk(self._lib.blsbn254_pairing_batch_dev(self._ctx, ctypes.c_void_p(d_g1), ctypes.c_void_p(d_g2), ctypes.c_size_t(n),

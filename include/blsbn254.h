@@ -145,18 +145,38 @@ int blsbn254_aggregate_finish(blsbn254_ctx* ctx, const uint8_t* partials /* k*38
 int blsbn254_aggregate_partial_with_sig(blsbn254_ctx* ctx, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
                                         const uint8_t* dst, size_t dst_len, const uint8_t agg_sig[64], uint8_t ml_out[384],
                                         int* all_pks_ok, int* sig_ok);
-/* Same result as blsbn254_verify_batch (same bitmap), computed with random linear combinations (SURVEY.md 8f
- * rank 4): groups of 16 tuples share ONE final exponentiation,
- *   prod_i [e(sig_i,-G2gen) e(H_i,pk_i)]^(r_i) = e(sum r_i sig_i, -G2gen) * prod_i e(r_i H_i, pk_i),
- * with 64-bit r_i = SHA-256(seed || i || pk_i || sig_i || H(msg_i)) (non-zero); a group whose product is not 1 is
- * re-verified tuple by tuple with the exact path, so a bit can only differ from verify_batch's when an invalid group
- * passes: probability about 2^-64 per group for a seed the adversary cannot predict.
+/* Same result as blsbn254_verify_batch (same bitmap), computed with random linear combinations (SURVEY.md 8f rank 4;
+ * bilinearity as in Gt::mul_by_scalar pairings.rs:585-600, multi_miller_loop over prepared keys pairings.rs:808-857).
+ *
+ * Batches that repeat keys (at most half as many distinct keys as tuples -- the same rule as verify_batch's prepared-key
+ * path): every run of one key, in key-sorted order, is cut into chunks of at most G tuples (default 16,
+ * blsbn254_set_rlc_group / BLSBN254_RLC_GROUP), and a chunk C with key pk is checked as ONE virtual tuple
+ *   e(sum_{i in C} r_i sig_i, -G2gen) * e(sum_{i in C} r_i H(msg_i), pk) == 1
+ * on the prepared-key verify path: 1/G as many Miller loops and final exponentiations.  The eligible tuples of a chunk that
+ * fails are re-verified one by one on the exact prepared-key path, so a bit can only differ from verify_batch's when an
+ * invalid chunk passes: probability about 2^-64 per chunk for a seed the adversary cannot predict.  Tuples whose
+ * signature does not decode / is the identity / is off the curve, or whose key fails its checks, are reported invalid
+ * directly and contribute to no sum.
+ * Weights: r_i = a_i + b_i lambda (lambda = eigenvalue of the G1 endomorphism (x, y) -> (beta x, y)), with the 32-bit
+ * a_i, b_i taken from SHA-256(seed || i || pk_i || sig_i || H(msg_i)); the 2^64 pairs give 2^64 distinct weights mod r.
+ * Batches of distinct keys: groups of 16 tuples in the caller's order share the signature-side Miller loop and the final
+ * exponentiation (host-pointer entry point; 64-bit weights), or take the exact path (device entry point).
  * seed = NULL (the production setting): the library draws 32 bytes from the OS (getrandom) inside the call, i.e. after
  * the batch is fixed.  A caller-supplied seed exists for reproducible tests; soundness then rests on that seed being
  * fresh and secret -- never reuse one, never derive it from public data. */
 int blsbn254_verify_batch_rlc(blsbn254_ctx* ctx, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off,
                               const uint8_t* sigs, size_t n, const uint8_t* dst, size_t dst_len,
                               const uint8_t seed[32], uint8_t* valid_bitmap);
+/* The same with every buffer device-resident (the layout of blsbn254_verify_batch_dev); seed and dst are host pointers. */
+int blsbn254_verify_batch_rlc_dev(blsbn254_ctx* ctx, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
+                                  const uint8_t* d_sigs, size_t n, const uint8_t* dst, size_t dst_len,
+                                  const uint8_t seed[32], uint8_t* d_valid_bitmap);
+/* tuples per chunk of the repeated-key variant: 2 <= group <= 4096 fixes it; 0 = automatic (the default): 16, raised to at
+ * most 32 when the larger chunk saves a whole round of waves on the device (chunk count just above a multiple of CUs x 256) */
+int blsbn254_set_rlc_group(blsbn254_ctx* ctx, size_t group);
+/* counters since context creation: out[0] tuples verified through chunks, out[1] chunks checked, out[2] tuples re-verified
+ * exactly after their chunk failed, out[3] tuples of distinct-key batches (no chunks) */
+int blsbn254_rlc_stats(blsbn254_ctx* ctx, uint64_t out[4]);
 /* impl Sum for G1Projective, g1.rs:561-565 */
 int blsbn254_aggregate_sigs(blsbn254_ctx* ctx, const uint8_t* sigs, size_t n, uint8_t out[64]);
 /* sum_i lambda_i * sig_i with Lagrange coefficients at 0 for the t distinct non-zero ids

@@ -1,25 +1,56 @@
-"""RLC vs exact verify at the bench workload (host-pointer entry points, wall time incl. PCIe staging)."""
+"""RLC batch verification vs the exact path at the bench workload: inputs resident in HBM (device entry points), kernel
+time by HIP events and wall time per step; three invalid rates, several chunk sizes.
+Usage: python scripts/bench_rlc.py [n] [groups, comma separated]  ->  JSON on stdout"""
 import json, os, sys, time
 sys.path.insert(0, os.getcwd())
+import numpy as np
+import torch
 import blsbn254_loader; M = blsbn254_loader.load()
 from oracle import oracle as O
 from tests import synth
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+groups = [int(g) for g in sys.argv[2].split(",")] if len(sys.argv) > 2 else [16]
 e = M.Engine(0); dst = M.DEFAULT_DST
-n = 262144
-out = {}
-for name, inv in (("1/64 invalid (bench workload)", 64), ("all valid", 0), ("1/1024 invalid", 1024)):
+dev = torch.device("cuda", 0)
+out = {"n": n, "pool": 1024}
+# the bench workload's invalid tuples (every 64th, key = index mod 1024) all fall on 16 of the 1024 keys; every 61st spreads them over all keys
+for name, inv in (("1/64 invalid (bench workload: invalid tuples on 16 keys)", 64), ("1/61 invalid (spread over all keys)", 61), ("all valid", 0),
+                  ("1/1021 invalid (spread over all keys)", 1021)):
     pks, msgs, sigs, exp = synth.make_batch_gpu(e, O, n, dst, pool=1024, invalid_every=inv, spot=50)
     want = synth.bitmap_of(exp)
+    data, off = M.engine.pack_messages(msgs)
+    t_pk = torch.frombuffer(bytearray(pks), dtype=torch.uint8).to(dev)
+    t_sg = torch.frombuffer(bytearray(sigs), dtype=torch.uint8).to(dev)
+    t_ms = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+    t_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    t_bm = torch.zeros((n + 7) // 8, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    args = (t_pk.data_ptr(), t_ms.data_ptr(), t_off.data_ptr(), t_sg.data_ptr(), n, t_bm.data_ptr(), dst)
     res = {}
-    for label, fn in (("exact", lambda: e.verify_batch(pks, msgs, sigs, dst)), ("rlc", lambda: e.verify_batch_rlc(pks, msgs, sigs, dst))):
-        assert fn() == want
+    runs = [("exact", None)] + [("rlc_g%d" % g if g else "rlc_auto", g) for g in groups]      # group 0 = automatic
+    for label, g in runs:
+        if g is not None:
+            e.set_rlc_group(g)
+        fn = (lambda: e.verify_batch_rlc_dev(*args)) if g is not None else (lambda: e.verify_batch_dev(*args))
+        t_bm.zero_()
+        fn(); e.synchronize()
+        assert bytes(t_bm.cpu().numpy()) == want, label
+        s0 = e.rlc_stats()
         e.profile_enable(True); e.profile_reset()
-        t = time.perf_counter(); reps = 3
-        for _ in range(reps): fn()
+        t = time.perf_counter(); reps = 5
+        for _ in range(reps):
+            fn()
+            e.synchronize()
         dt = (time.perf_counter() - t) / reps
         p = e.profile_read(); e.profile_enable(False)
+        s1 = e.rlc_stats()
         kms = sum(v["total_ms"] for v in p.values()) / reps
-        res[label] = {"wall_ms": round(dt * 1e3, 2), "kernel_ms": round(kms, 2), "verifies_per_s_kernels": round(n / (kms * 1e-3)),
-                      "kernels": {k: round(v["total_ms"] / reps, 2) for k, v in p.items() if v["total_ms"] / reps > 0.3}}
+        res[label] = {"wall_ms": round(dt * 1e3, 2), "verifies_per_s": round(n / dt), "kernel_ms_sum": round(kms, 2),
+                      "kernels": {k: round(v["total_ms"] / reps, 2) for k, v in p.items() if v["total_ms"] / reps > 0.05}}
+        if g is not None:
+            res[label]["chunks_per_step"] = (s1["chunks"] - s0["chunks"]) // reps
+            res[label]["fallback_tuples_per_step"] = (s1["fallback_tuples"] - s0["fallback_tuples"]) // reps
     out[name] = res
+e.set_rlc_group(0)
 print(json.dumps(out, indent=1))

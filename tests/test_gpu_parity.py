@@ -463,6 +463,88 @@ def test_verify_batch_rlc_adversarial_pairs(eng, oracle, pyref, M):
         assert eng.verify_batch_rlc(pks, msgs, sigs, dst, seed=bytes([t]) * 32) == b"\x00"
 
 
+def test_verify_batch_rlc_repeated_keys_cancelling_errors_in_one_chunk(eng, oracle, pyref, M):
+    """Repeated-key RLC path: two signatures under the SAME key whose errors cancel in an unweighted sum land in the same
+    chunk; the random weights must catch them, and the honest tuples of that chunk must still come out valid (fallback)."""
+    dst = M.DEFAULT_DST
+    sk = synth.sk_of(0)
+    pk = oracle.sk_to_pk(sk)
+    msgs = [b"m%d" % i for i in range(6)]
+    good = [oracle.sign(sk, m, dst) for m in msgs]
+    D = oracle.g1_mul(oracle.g1_generator(), 777)
+    negD = D[:32] + (pyref.P - int.from_bytes(D[32:], "big")).to_bytes(32, "big")
+    sigs = oracle.g1_add(good[0], D) + oracle.g1_add(good[1], negD) + b"".join(good[2:])
+    want = bytes([0b111100])
+    assert eng.verify_batch(pk * 6, msgs, sigs, dst) == want
+    before = eng.rlc_stats()
+    for t in range(4):
+        assert eng.verify_batch_rlc(pk * 6, msgs, sigs, dst, seed=bytes([t + 1]) * 32) == want
+    after = eng.rlc_stats()
+    assert after["chunked_tuples"] - before["chunked_tuples"] == 24          # the repeated-key path ran ...
+    assert after["fallback_tuples"] - before["fallback_tuples"] == 24        # ... and every chunk failed: all six re-verified exactly
+
+
+@pytest.mark.parametrize("group", [2, 3, 16, 100])
+def test_verify_batch_rlc_repeated_keys_group_sizes(eng, oracle, M, group):
+    """Chunk sizes that do and do not divide the runs; keys of very different multiplicity (1 ... hundreds), one invalid key,
+    invalid tuples of every kind; bitmap == exact path == closed-form expectation, and the counters add up."""
+    dst = M.DEFAULT_DST
+    n = 1500
+    pks, msgs, sigs, exp = synth.make_batch(oracle, n, dst, pool=7, invalid_every=9, uniq=60)
+    # skew the multiplicities: the last 300 tuples all use the key of tuple 0 (most of their signatures become wrong); the
+    # expectation for that tail comes from the CPU oracle
+    pks = pks[:128 * (n - 300)] + pks[:128] * 300
+    tail = oracle.verify_batch(pks[128 * (n - 300):], msgs[n - 300:], sigs[64 * (n - 300):], dst, nthreads=8)
+    want = synth.bitmap_of(exp[:n - 300]) + tail
+    assert 0 < sum(bin(b).count("1") for b in tail) < 300
+    assert eng.verify_batch(pks, msgs, sigs, dst) == want
+    eng.set_rlc_group(group)
+    try:
+        before = eng.rlc_stats()
+        assert eng.verify_batch_rlc(pks, msgs, sigs, dst) == want
+        after = eng.rlc_stats()
+    finally:
+        eng.set_rlc_group(0)                      # back to automatic
+    assert after["chunked_tuples"] - before["chunked_tuples"] == n
+    assert (n + group - 1) // group <= after["chunks"] - before["chunks"] <= n // group + 9      # at most one partial chunk per distinct key
+    assert 0 < after["fallback_tuples"] - before["fallback_tuples"] <= n
+
+
+def test_verify_batch_rlc_all_valid_has_no_fallback(eng, oracle, M):
+    dst = M.DEFAULT_DST
+    n = 2048
+    pks, msgs, sigs, exp = synth.make_batch_gpu(eng, oracle, n, dst, pool=16, invalid_every=0, spot=20)
+    before = eng.rlc_stats()
+    assert eng.verify_batch_rlc(pks, msgs, sigs, dst) == synth.bitmap_of(exp) == b"\xff" * (n // 8)
+    after = eng.rlc_stats()
+    assert after["chunked_tuples"] - before["chunked_tuples"] == n
+    assert after["chunks"] - before["chunks"] == n // 16
+    assert after["fallback_tuples"] == before["fallback_tuples"]
+
+
+def test_verify_batch_rlc_dev_full_size(eng, oracle, M):
+    """BASELINE configs[1] size through the device entry point: same bitmap as verify_batch_dev and as the closed form."""
+    import torch
+    dst = M.DEFAULT_DST
+    n = 262144
+    pks, msgs, sigs, exp = synth.make_batch_gpu(eng, oracle, n, dst, pool=1024, invalid_every=64, spot=50)
+    data, off = M.engine.pack_messages(msgs)
+    dev = torch.device("cuda", 0)
+    t_pk = torch.frombuffer(bytearray(pks), dtype=torch.uint8).to(dev)
+    t_sg = torch.frombuffer(bytearray(sigs), dtype=torch.uint8).to(dev)
+    t_ms = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+    t_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    t_a = torch.zeros((n + 7) // 8, dtype=torch.uint8, device=dev)
+    t_b = torch.zeros((n + 7) // 8, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    eng.verify_batch_dev(t_pk.data_ptr(), t_ms.data_ptr(), t_off.data_ptr(), t_sg.data_ptr(), n, t_a.data_ptr(), dst)
+    eng.verify_batch_rlc_dev(t_pk.data_ptr(), t_ms.data_ptr(), t_off.data_ptr(), t_sg.data_ptr(), n, t_b.data_ptr(), dst)
+    eng.synchronize()
+    want = synth.bitmap_of(exp)
+    assert bytes(t_a.cpu().numpy()) == want
+    assert bytes(t_b.cpu().numpy()) == want
+
+
 def test_chunked_entry_points(oracle, pyref, M, monkeypatch):
     """Batches larger than the per-launch chunk (4 Mi tuples in production; forced to 64 here through the
     BLSBN254_CHUNK_LANES test knob) are processed chunk by chunk: same results as the one-launch path."""
