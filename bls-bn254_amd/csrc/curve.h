@@ -333,18 +333,52 @@ BN_FUNC G1A svdw_g1_finish(const Fp& u_in, const Fp& tv3) {       // tv3 = inv0(
   return r;
 }
 BN_FUNC G1A svdw_g1(const Fp& u) { return svdw_g1_finish(u, fp_inv(svdw_g1_den(u))); }
-// hash_to_curve for G1 (g1.rs:910-919): map two field elements, add, no cofactor.  One inversion serves both
-// maps (1/(d0 d1), then times d1 and d0); a zero denominator keeps the map's inv0(0) = 0.
-// the sum of the two mapped points in homogeneous coordinates (no final inversion)
+// The same map WITHOUT the inversion, for hash_to_curve (whose sum of two mapped points is projective anyway): every candidate
+// x_i is kept as a fraction N_i / D_i --
+//   x1, x2 = (c2 tv2 -+ c3 u) / tv2,    x3 = Z + c4 (tv2^2 tv3)^2 = (tv1^2 + c4 tv2^2) / tv1^2      (tv3 = 1 / (tv1 tv2))
+// -- g(x_i) = (N_i^3 + 3 D_i^3) / D_i^3 is a square iff (N_i^3 + 3 D_i^3) D_i is (Jacobi symbol), and the affine y of the
+// selected candidate comes from ONE power (sqrt_ratio, fp.rs:212-243 with v = D^3): y = U V (U V^3)^((p-3)/4), y^2 = U / V.
+// Two powers per map (inv0 + square root) become one; the point is the reference's (same x, same y, same sign rule).
+// inv0(0) = 0 in the reference (tv1 tv2 = 0): x1 = x2 = c2, x3 = Z = 1.
+struct SvdwFrac { Fp n, d, y; };                         // x = n / d (d != 0), y affine
+BN_FUNC SvdwFrac svdw_g1_frac(const Fp& u_in) {
+  BN_CTX;
+  const Fp u = fp_norm(u_in);
+  const Fp c2 = fp_const(bnc::SVDW1_C2), c3 = fp_const(bnc::SVDW1_C3), c4 = fp_const(bnc::SVDW1_C4), one = fp_one();
+  const Fp u2 = fp_sqr(u);
+  Fp tv1 = fp_lc2<4, 0>(u2, u2);                                   // c1 = g(Z) = 4
+  const Fp tv2 = fp_norm(fp_add(one, tv1));
+  tv1 = fp_norm(fp_sub(one, tv1));
+  const bool exc = fp_is_zero(tv1) | fp_is_zero(tv2);
+  const Fp c3u = fp_mul(c3, u), c2t = fp_mul(c2, tv2);
+  const Fp n1 = fp_select(exc, c2, fp_norm(fp_sub(c2t, c3u))), n2 = fp_select(exc, c2, fp_norm(fp_add(c2t, c3u)));
+  const Fp d12 = fp_select(exc, one, tv2);
+  const Fp t1s = fp_sqr(tv1);
+  const Fp d3 = fp_select(exc, one, fp_norm(t1s));
+  const Fp n3 = fp_select(exc, one, fp_norm(fp_add(t1s, fp_mul(c4, fp_sqr(tv2)))));
+  const Fp v12 = fp_mul(fp_sqr(d12), d12), v3 = fp_mul(fp_sqr(d3), d3);        // D^3
+  const Fp g1n = fp_norm(fp_add(fp_mul(fp_sqr(n1), n1), fp_lc2<3, 0>(v12, v12)));   // N^3 + 3 D^3
+  const Fp g2n = fp_norm(fp_add(fp_mul(fp_sqr(n2), n2), fp_lc2<3, 0>(v12, v12)));
+  const Fp g3n = fp_norm(fp_add(fp_mul(fp_sqr(n3), n3), fp_lc2<3, 0>(v3, v3)));
+  // g(x3) is a square whenever g(x1) and g(x2) are not (the product of the three is one)
+  const bool e1 = fp_is_square(fp_mul(g1n, d12)), e2 = fp_is_square(fp_mul(g2n, d12));
+  SvdwFrac r;
+  r.n = fp_select(e1, n1, fp_select(e2, n2, n3));
+  r.d = fp_select(e1 | e2, d12, d3);
+  const Fp U = fp_select(e1, g1n, fp_select(e2, g2n, g3n)), V = fp_select(e1 | e2, v12, v3);
+  const Fp V3 = fp_mul(fp_sqr(V), V);
+  const Fp y = fp_mul(fp_mul(U, V), fp_pow(fp_mul(U, V3), BN_EXP(EXP_PM3_4)));
+  const bool flip = fp_sgn0(u) != fp_sgn0(y);
+  r.y = fp_select(flip, fp_norm(fp_neg(y)), y);
+  return r;
+}
+// hash_to_curve for G1 (g1.rs:910-919): map two field elements, add, no cofactor.  No inversion at all: the mapped points
+// enter the complete addition as (N : y D : D); the sum stays in homogeneous coordinates.
 BN_FUNC G1P hash_to_g1_from_fields_proj(const Fp& u0, const Fp& u1) {
   BN_CTX;
-  Fp d0 = svdw_g1_den(u0), d1 = svdw_g1_den(u1);
-  bool z0 = fp_is_zero(d0), z1 = fp_is_zero(d1);
-  Fp e0 = fp_select(z0, fp_one(), d0), e1 = fp_select(z1, fp_one(), d1);
-  Fp inv = fp_inv(fp_mul(e0, e1));
-  Fp i0 = fp_select(z0, fp_zero(), fp_mul(inv, e1)), i1 = fp_select(z1, fp_zero(), fp_mul(inv, e0));
-  G1A q0 = svdw_g1_finish(u0, i0), q1 = svdw_g1_finish(u1, i1);
-  return proj_add(proj_from_affine(q0), proj_from_affine(q1));
+  const SvdwFrac a = svdw_g1_frac(u0), b = svdw_g1_frac(u1);
+  const G1P q0 = {a.n, fp_mul(a.y, a.d), a.d}, q1 = {b.n, fp_mul(b.y, b.d), b.d};
+  return proj_add(q0, q1);
 }
 BN_FUNC G1A hash_to_g1_from_fields(const Fp& u0, const Fp& u1) { return g1_to_affine(hash_to_g1_from_fields_proj(u0, u1)); }
 

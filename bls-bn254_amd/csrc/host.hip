@@ -53,7 +53,7 @@ struct blsbn254_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   uint32_t kd_seed = 0;              // per-context random seed of the key hash table
   bool auto_prepare = true;          // verify_batch: de-duplicate the public keys and prepare each distinct key once (BLSBN254_AUTO_PREPARE=0 disables)
-  uint64_t stat_prepared_chunks = 0, stat_exact_chunks = 0;
+  uint64_t stat_prepared_chunks = 0, stat_exact_chunks = 0, stat_grouped_aggregates = 0, stat_pairwise_aggregates = 0;
   DevBuf q_ws;           // decoded public keys of the two-pairs-per-lane Miller kernel, 72 x lanes limbs
   DevBuf th_x, th_num, th_den, th_glv, th_part, th_part2;   // threshold combine: ids, partial products, GLV halves, window sums
   DevBuf fe_slots;       // the ten named powers of the t -> t^x addition chain, 10 x 108 x n limbs
@@ -768,6 +768,11 @@ int blsbn254_path_stats(blsbn254_ctx* c, uint64_t out[2]) {
   out[0] = c->stat_prepared_chunks; out[1] = c->stat_exact_chunks;
   return 0;
 }
+int blsbn254_aggregate_path_stats(blsbn254_ctx* c, uint64_t out[2]) {
+  if (!c || !out) return BLSBN254_E_ARG;
+  out[0] = c->stat_grouped_aggregates; out[1] = c->stat_pairwise_aggregates;
+  return 0;
+}
 int blsbn254_set_auto_prepare(blsbn254_ctx* c, int on) { if (!c) return BLSBN254_E_ARG; c->auto_prepare = on != 0; return 0; }
 
 // ---------------- random-linear-combination batch verification over repeated keys (k_rlc2.hip)
@@ -1054,8 +1059,11 @@ static int fp12_tree(blsbn254_ctx* c, int32_t* a, size_t cnt, size_t sa, int32_t
 // prod_i ML(H(msg_i), pk_i) over the caller's n pairs, optionally times ML(extra_sig, -G2gen): the aggregate signature
 // then simply joins the batch as pair n (one more lane half among the million) instead of a latency-bound one-lane launch.
 // Two pairs per lane sharing one f^2 (k_miller_hpk2), then the pairwise product tree.
+// staged = true: the caller (aggregate_verify_grouped, which found the keys distinct) has already put dst, messages, keys and
+// the signature where this function stages them
 static int aggregate_partial_impl(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
-                                  const uint8_t* dst, size_t dst_len, const uint8_t* extra_sig, uint8_t ml_out[384], int* all_pks_ok, int* sig_ok) {
+                                  const uint8_t* dst, size_t dst_len, const uint8_t* extra_sig, uint8_t ml_out[384], int* all_pks_ok, int* sig_ok,
+                                  bool staged = false) {
   *all_pks_ok = 1;
   if (sig_ok) *sig_ok = 1;
   const size_t np = n + (extra_sig ? 1 : 0);                 // pairs in the loop
@@ -1064,21 +1072,23 @@ static int aggregate_partial_impl(blsbn254_ctx* c, const uint8_t* pks, const uin
   HIPCHK(c, hipSetDevice(c->device));
   uint32_t dl = 0; int rc;
   if (n) {
-    rc = stage_dst(c, dst, dst_len, &dl);
+    rc = stage_dst(c, dst, dst_len, &dl);                    // (a no-op when the tag is already resident)
     if (rc) return rc;
-    rc = stage_msgs(c, msgs, off, n);
-    if (rc) return rc;
+    if (!staged) {
+      rc = stage_msgs(c, msgs, off, n);
+      if (rc) return rc;
+    }
   }
   const size_t n_lanes = (np + 1) / 2;
   HIPCHK(c, c->in_a.reserve(128 * np)); HIPCHK(c, c->in_b.reserve(64)); HIPCHK(c, c->h_ws.reserve(np * 18 * 4)); HIPCHK(c, c->f_ws.reserve(n_lanes * 108 * 4));
   HIPCHK(c, c->q_ws.reserve(n_lanes * 72 * 4));
   HIPCHK(c, c->flags.reserve(np)); HIPCHK(c, c->sub_ok.reserve(np)); HIPCHK(c, c->misc.reserve(64)); HIPCHK(c, c->out.reserve(384));
-  if (n) HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * n, hipMemcpyHostToDevice, c->stream));
+  if (n && !staged) HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * n, hipMemcpyHostToDevice, c->stream));
   int32_t* f = (int32_t*)c->f_ws.p;
   int* d_ok = (int*)c->misc.p;                               // [0] all keys valid, [1] (byte) signature valid
   static const int ones[2] = {1, 1};
   HIPCHK(c, hipMemcpyAsync(d_ok, ones, 8, hipMemcpyHostToDevice, c->stream));
-  if (extra_sig) {
+  if (extra_sig && !staged) {
     HIPCHK(c, hipMemcpyAsync(c->in_b.p, extra_sig, 64, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync((uint8_t*)c->in_a.p + 128 * n, NEG_G2_BYTES, 128, hipMemcpyHostToDevice, c->stream));
   }
@@ -1183,6 +1193,112 @@ int blsbn254_aggregate_finish(blsbn254_ctx* c, const uint8_t* partials, size_t k
   *valid = (sig_ok && h_one == 1) ? 1 : 0;
   return 0;
 }
+// Aggregate verify over a batch that repeats public keys, by bilinearity in the first argument (exact, no randomness):
+//   prod_i e(H_i, pk_(k_i)) = prod_k e( sum_{i: k_i = k} H_i , pk_k )
+// so only one Miller loop per DISTINCT key (plus the signature's pair) runs, after n G1 additions: key de-duplication and
+// key-sorted order as in verify_batch, the sums by levels of chunks of AGG_SUM_GROUP points (k_g1_seg_sum), the u + 1 pairs on the
+// prepared two-pairs-per-lane loop, product tree, ONE final exponentiation.  The boolean is aggregate_verify's; the Miller
+// value is not the product of the n per-pair values (blsbn254_aggregate_partial keeps that bit-exact form for the sharded API).
+// *took = false: keys do not repeat, nothing was done.
+static const size_t AGG_SUM_GROUP = 32;
+static int aggregate_verify_grouped(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t agg_sig[64],
+                                    const uint8_t* dst, size_t dst_len, int* valid, bool* took) {
+  *took = false;
+  HIPCHK(c, hipSetDevice(c->device));
+  uint32_t dl = 0;
+  int rc = stage_dst(c, dst, dst_len, &dl);
+  if (rc) return rc;
+  rc = stage_msgs(c, msgs, off, n);
+  if (rc) return rc;
+  HIPCHK(c, c->in_a.reserve(128 * (n + 1))); HIPCHK(c, c->in_b.reserve(64));
+  HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * n, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync((uint8_t*)c->in_a.p + 128 * n, NEG_G2_BYTES, 128, hipMemcpyHostToDevice, c->stream));   // "tuple n": the key of the signature's pair
+  HIPCHK(c, hipMemcpyAsync(c->in_b.p, agg_sig, 64, hipMemcpyHostToDevice, c->stream));
+  size_t u = 0;
+  rc = dedup_keys(c, (const uint8_t*)c->in_a.p, n, &u);
+  if (rc) return rc;
+  if (!(u * 2 <= n && u + 1 <= PREP_MAX_KEYS)) return 0;
+  *took = true;
+  const size_t G = AGG_SUM_GROUP, np = u + 1, n_lanes = (np + 1) / 2;
+  const uint32_t n32 = (uint32_t)n, u32 = (uint32_t)u, G32 = (uint32_t)G;
+  // the u keys and -G2gen (key id u) become line tables on the second stream, beside the hashing
+  const uint32_t last_key = n32;
+  HIPCHK(c, hipMemcpyAsync((uint32_t*)c->kd_keys.p + u, &last_key, 4, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));                                   // last_key and the staged copies are consumed
+  HIPCHK(c, c->prep_ok.reserve(np)); HIPCHK(c, c->prep_raw.reserve(np * PREP_RAW_LIMBS * 4));
+  HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+  HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+  LAUNCH2(c, "g2_prepare", k_g2_prepare, np, (const uint8_t*)c->in_a.p, (const uint32_t*)c->kd_keys.p, (uint32_t)np, (int32_t*)c->prep_raw.p, (uint8_t*)c->prep_ok.p);
+  HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
+  // key ids, key-sorted order
+  const size_t m1_max = n / G + u;
+  HIPCHK(c, c->h_ws.reserve(n * 27 * 4)); HIPCHK(c, c->kd_cursor.reserve(4 * (u + 1))); HIPCHK(c, c->kd_perm.reserve(4 * n)); HIPCHK(c, c->r2_tchunk.reserve(4 * n));
+  HIPCHK(c, c->r2_ccnt.reserve(4 * (u + 2))); HIPCHK(c, c->r2_cbase.reserve(4 * (u + 2))); HIPCHK(c, c->r2_bcnt.reserve(4 * (u + 2))); HIPCHK(c, c->r2_bbase.reserve(4 * (u + 2)));
+  HIPCHK(c, c->r2_ckid.reserve(4 * m1_max)); HIPCHK(c, c->r2_list.reserve(4 * m1_max)); HIPCHK(c, c->r2_cstart.reserve(4 * m1_max)); HIPCHK(c, c->r2_clen.reserve(4 * m1_max));
+  HIPCHK(c, c->r2_iota.reserve(4 * m1_max)); HIPCHK(c, c->r2_a.reserve(27 * 4 * m1_max)); HIPCHK(c, c->r2_b.reserve(27 * 4 * m1_max));
+  HIPCHK(c, c->f_ws.reserve(n_lanes * 108 * 4)); HIPCHK(c, c->flags.reserve(np)); HIPCHK(c, c->status.reserve(np + 8)); HIPCHK(c, c->misc.reserve(64));
+  HIPCHK(c, c->rlc_b.reserve(np * 18 * 4)); HIPCHK(c, c->rlc_idx.reserve(4 * np));
+  uint32_t *hist = (uint32_t*)c->kd_hist.p, *cursor = (uint32_t*)c->kd_cursor.p, *perm = (uint32_t*)c->kd_perm.p, *kid = (uint32_t*)c->kd_kid.p;
+  HIPCHK(c, hipMemsetAsync(hist, 0, 4 * u, c->stream));
+  LAUNCH(c, "kd_propagate", k_kd_propagate, n, (const uint32_t*)c->kd_rep.p, n32, u32, kid, hist);
+  { ProfScope ps_(c, "kd_scan"); hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)hist, u32, cursor); }
+  HIPCHK(c, hipGetLastError());
+  LAUNCH(c, "kd_scatter", k_kd_scatter, n, (const uint32_t*)kid, n32, u32, cursor, perm);          // cursor[k] is now the END of run k
+  LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, n, (uint8_t*)nullptr, 3);
+  LAUNCH(c, "iota", k_iota_u32, m1_max, (uint32_t*)c->r2_iota.p, (uint32_t)m1_max);
+  // sums per key, level by level: items (level 0: the tuples in sorted order; later: the chunk sums of the level before, which
+  // are in key order too) -> chunks of at most G items of one key -> one sum per chunk, until every key has ONE chunk
+  const int32_t* pts = (const int32_t*)c->h_ws.p; size_t pts_stride = n; const uint32_t* it_perm = perm; const uint32_t* it_kid = kid;
+  const uint32_t* it_hist = hist; const uint32_t* it_end = cursor;
+  uint32_t *cnt_a = (uint32_t*)c->r2_ccnt.p, *base_a = (uint32_t*)c->r2_cbase.p, *cnt_b = (uint32_t*)c->r2_bcnt.p, *base_b = (uint32_t*)c->r2_bbase.p;
+  uint32_t *ckid_a = (uint32_t*)c->r2_ckid.p, *ckid_b = (uint32_t*)c->r2_list.p;
+  int32_t *out_a = (int32_t*)c->r2_a.p, *out_b = (int32_t*)c->r2_b.p;
+  size_t items = n;
+  for (int level = 0; ; ++level) {
+    if (level > 8) { c->last_error = "internal: key sums do not converge"; return BLSBN254_E_HIP; }
+    LAUNCH(c, "rlc2_counts", k_rlc2_chunk_counts, u + 1, it_hist, u32, G32, cnt_a);
+    { ProfScope ps_(c, "kd_scan"); hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)cnt_a, u32 + 1, base_a); }
+    HIPCHK(c, hipGetLastError());
+    uint32_t m32 = 0;
+    HIPCHK(c, hipMemcpyAsync(&m32, base_a + u, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t m = m32;
+    if (m < u || m > m1_max || m > items) { c->last_error = "internal: chunk count out of range"; return BLSBN254_E_HIP; }
+    LAUNCH(c, "rlc2_mark", k_rlc2_mark, items, it_perm, it_kid, it_hist, it_end, (const uint32_t*)base_a, (uint32_t)items, G32,
+           (uint32_t*)c->r2_tchunk.p, ckid_a, (uint32_t*)c->r2_cstart.p, (uint32_t*)c->r2_clen.p);
+    LAUNCH(c, "g1_seg_sum", k_g1_seg_sum, m, pts, pts_stride, level == 0 ? (const uint32_t*)perm : (const uint32_t*)nullptr, (const uint32_t*)c->r2_cstart.p,
+           (const uint32_t*)c->r2_clen.p, m, out_a, m);
+    pts = out_a; pts_stride = m; items = m;
+    if (m == u) break;                                                          // one chunk per key: chunk index == key id
+    // next level: item j has key ckid_a[j]; key k owns items base_a[k] .. base_a[k + 1]
+    it_perm = (const uint32_t*)c->r2_iota.p; it_kid = ckid_a; it_hist = cnt_a; it_end = base_a + 1;
+    std::swap(cnt_a, cnt_b); std::swap(base_a, base_b); std::swap(ckid_a, ckid_b); std::swap(out_a, out_b);
+  }
+  // the u + 1 pairs: (sum_k, pk_k) for k < u and (agg_sig, -G2gen) as pair u with key id u
+  int32_t* h2 = (int32_t*)c->rlc_b.p; uint8_t* st = (uint8_t*)c->status.p; uint32_t* kid2 = (uint32_t*)c->rlc_idx.p;
+  int* d_ok = (int*)c->misc.p;                                                  // [0] all keys valid, [1] (byte) signature valid, [4] is_one
+  static const int ones[2] = {1, 1};
+  HIPCHK(c, hipMemcpyAsync(d_ok, ones, 8, hipMemcpyHostToDevice, c->stream));
+  LAUNCH(c, "g1p_to_h", k_g1p_to_h_affine, u, pts, pts_stride, u, h2, np, st);
+  HIPCHK(c, hipMemsetAsync(st + u, 1, 1, c->stream));
+  LAUNCH(c, "g1_to_ws", k_g1_to_ws, 1, (const uint8_t*)c->in_b.p, h2, u, np, (uint8_t*)(d_ok + 1));
+  LAUNCH(c, "iota", k_iota_u32, np, kid2, (uint32_t)np);
+  HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+  LAUNCH(c, "miller_hpk2p", k_miller_hpk2p, n_lanes, (const int32_t*)h2, np, (const uint32_t*)kid2, (const int32_t*)c->prep_raw.p, (const uint8_t*)c->prep_ok.p, np,
+         (int32_t*)c->f_ws.p, n_lanes, (uint8_t*)c->flags.p, (const uint8_t*)st);
+  LAUNCH(c, "and_reduce", k_and_reduce, u, (const uint8_t*)c->flags.p, (const uint8_t*)c->flags.p, u, d_ok);
+  int32_t* res; size_t rs;
+  rc = fp12_tree(c, (int32_t*)c->f_ws.p, n_lanes, n_lanes, &res, &rs);
+  if (rc) return rc;
+  rc = run_final_exp(c, res, 1, rs, 3, nullptr, nullptr, nullptr, nullptr, d_ok + 4);
+  if (rc) return rc;
+  int h[5] = {0, 0, 0, 0, 0};
+  HIPCHK(c, hipMemcpyAsync(h, d_ok, 20, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *valid = (h[0] == 1 && (h[1] & 0xff) == 1 && h[4] == 1) ? 1 : 0;
+  ++c->stat_grouped_aggregates;
+  return 0;
+}
 int blsbn254_aggregate_verify(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
                               const uint8_t agg_sig[64], const uint8_t* dst, size_t dst_len, int* valid) {
   if (!c || !valid || !agg_sig || !off || (n && !pks) || (dst_len && !dst)) return BLSBN254_E_ARG;
@@ -1190,7 +1306,16 @@ int blsbn254_aggregate_verify(blsbn254_ctx* c, const uint8_t* pks, const uint8_t
   if (n == 0) return 0;
   if (n + 1 > MAX_LANES) { c->last_error = "more than 2^23 - 1 pairs in one aggregate_verify call"; return BLSBN254_E_ARG; }
   uint8_t ml[384]; int ok = 0, sig_ok = 0, v = 0;
-  int rc = aggregate_partial_impl(c, pks, msgs, off, n, dst, dst_len, agg_sig, ml, &ok, &sig_ok);
+  int rc;
+  bool staged = false;
+  if (c->auto_prepare && n >= 1024) {                  // repeated keys: one pair per distinct key
+    bool took = false;
+    rc = aggregate_verify_grouped(c, pks, msgs, off, n, agg_sig, dst, dst_len, valid, &took);
+    if (rc || took) return rc;
+    staged = true;
+  }
+  ++c->stat_pairwise_aggregates;
+  rc = aggregate_partial_impl(c, pks, msgs, off, n, dst, dst_len, agg_sig, ml, &ok, &sig_ok, staged);
   if (rc) return rc;
   rc = blsbn254_aggregate_finish(c, ml, 1, nullptr, &v);
   if (rc) return rc;

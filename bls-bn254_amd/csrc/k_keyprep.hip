@@ -96,10 +96,26 @@ __global__ void __launch_bounds__(1024) k_scan_excl(const uint32_t* hist, uint32
   uint32_t run = t ? part[t - 1] : 0;
   for (uint32_t k = lo; k < hi; ++k) { cursor[k] = run; run += hist[k]; }
 }
-__global__ void k_kd_scatter(const uint32_t* kid, uint32_t n, uint32_t u, uint32_t* cursor, uint32_t* perm) {
-  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n || kid[i] >= u) return;
-  perm[atomicAdd(&cursor[kid[i]], 1u)] = i;
+// perm: the tuples in key-sorted order (order within a key: arbitrary).  When the key ids fit (u <= 8192) a workgroup first
+// ranks its tuples per key in LDS and reserves each key's range with ONE global atomic, so that a batch over a handful of
+// keys does not serialise a million increments on a few addresses (2.4 ms for 2^20 tuples over 8 keys before).
+__global__ void __launch_bounds__(256) k_kd_scatter(const uint32_t* kid, uint32_t n, uint32_t u, uint32_t* cursor, uint32_t* perm) {
+  __shared__ uint32_t cnt[8192];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < n && kid[i] < u;
+  if (u > 8192u) {
+    if (live) perm[atomicAdd(&cursor[kid[i]], 1u)] = i;
+    return;
+  }
+  for (uint32_t k = threadIdx.x; k < u; k += blockDim.x) cnt[k] = 0;
+  __syncthreads();
+  const uint32_t k = live ? kid[i] : 0;
+  uint32_t rank = 0;
+  if (live) rank = atomicAdd(&cnt[k], 1u);
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < u; j += blockDim.x) { const uint32_t v = cnt[j]; if (v) cnt[j] = atomicAdd(&cursor[j], v); }   // count -> base
+  __syncthreads();
+  if (live) perm[cnt[k] + rank] = i;
 }
 // lines + validity of u keys.  keys == NULL: key k is pks[128 k]; else key k is the public key of tuple keys[k].
 // table: u x 88 x 54 limbs, key-major contiguous.

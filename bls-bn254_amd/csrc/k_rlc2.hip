@@ -57,8 +57,9 @@ BN_KERNEL k_rlc2_prep(const uint32_t* perm, const uint8_t* pks, const uint8_t* s
   G1A gp; gp.x = fp_one(); gp.y = fp_norm(fp_add(fp_one(), fp_one())); gp.inf = false;
   sig.x = fp_select(ok, sig.x, gp.x); sig.y = fp_select(ok, sig.y, gp.y); sig.inf = false;
   const G1P id = proj_identity<Fp>();
-  const G1P p1 = proj_from_affine(sig), p1f = g1_phi(p1), p1s = proj_add(p1, p1f);
-  const G1P p2 = load_g1p(h_ws + i, n), p2f = g1_phi(p2), p2s = proj_add(p2, p2f);
+  // P + phi(P) = -phi^2(P) = (beta^2 x, -y) with beta^2 = -1 - beta (lambda^2 + lambda + 1 = 0): no addition needed for the third table entry
+  const G1P p1 = proj_from_affine(sig), p1f = g1_phi(p1), p1s = {fp_norm(fp_neg(fp_add(p1.x, p1f.x))), fp_norm(fp_neg(p1.y)), p1.z};
+  const G1P p2 = load_g1p(h_ws + i, n), p2f = g1_phi(p2), p2s = {fp_norm(fp_neg(fp_add(p2.x, p2f.x))), fp_norm(fp_neg(p2.y)), p2.z};
   G1P acc1 = id, acc2 = id;
 #pragma unroll 1
   for (int j = 31; j >= 0; --j) {                       // the two chains are independent: they fill each other's latency
@@ -147,4 +148,31 @@ __global__ void __launch_bounds__(256) k_rlc2_compact(const uint8_t* need, const
   uint32_t base = block_base[blockIdx.x];
   for (uint32_t k = 0; k < w; ++k) base += wave_cnt[k];
   if (nd) list[base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = perm[s];
+}
+
+// ---- sums of G1 points per key (aggregate verify over repeated keys: prod_{i in S_k} e(H_i, pk_k) = e(sum_{i in S_k} H_i, pk_k))
+// One lane per chunk: out[c] = sum of the chunk's members.  Member s (a position in key-sorted order) is the point in column
+// perm[s] (or s when perm is NULL) of the limb-major homogeneous array in_ws.
+BN_KERNEL k_g1_seg_sum(const int32_t* in_ws, size_t in_stride, const uint32_t* perm, const uint32_t* chunk_start, const uint32_t* chunk_len, size_t m,
+                       int32_t* out_ws, size_t out_stride) {
+  const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= m) return;
+  const size_t s0 = chunk_start[c];
+  const uint32_t len = chunk_len[c];
+  G1P acc = proj_identity<Fp>();
+#pragma unroll 1
+  for (uint32_t j = 0; j < len; ++j) acc = proj_add(acc, load_g1p(in_ws + (perm ? perm[s0 + j] : s0 + j), in_stride));
+  store_g1p(out_ws + c, out_stride, acc);
+}
+// u sums (homogeneous) -> affine limbs in slots 0..u-1 of an H workspace (18 x h_stride); status[k] bit 1 = the sum is the identity
+// (that pair contributes 1 to the Miller product; the generator stands in for it), bit 0 always set.
+BN_KERNEL k_g1p_to_h_affine(const int32_t* in_ws, size_t in_stride, size_t u, int32_t* h_ws, size_t h_stride, uint8_t* status) {
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= u) return;
+  G1P p = load_g1p(in_ws + k, in_stride);
+  const bool inf = fp_is_zero(p.z);
+  G1A gp; gp.x = fp_one(); gp.y = fp_norm(fp_add(fp_one(), fp_one())); gp.inf = false;
+  const G1A a = g1_to_affine(proj_select(inf, proj_from_affine(gp), p));
+  store_fp(h_ws + k, h_stride, a.x); store_fp(h_ws + 9 * h_stride + k, h_stride, a.y);
+  status[k] = (uint8_t)(1 | (inf ? 2 : 0));
 }

@@ -75,6 +75,9 @@ __global__ void __launch_bounds__(256) k_rlc2_resolve(const uint32_t* perm, cons
                                                       const uint8_t* key_ok, const uint8_t* c_state, const uint8_t* c_isone, const uint8_t* c_flags,
                                                       uint32_t n, uint8_t* valid, uint8_t* need, uint32_t* block_cnt);
 __global__ void __launch_bounds__(256) k_rlc2_compact(const uint8_t* need, const uint32_t* perm, uint32_t n, const uint32_t* block_base, uint32_t* list);
+BN_KERNEL k_g1_seg_sum(const int32_t* in_ws, size_t in_stride, const uint32_t* perm, const uint32_t* chunk_start, const uint32_t* chunk_len, size_t m,
+                       int32_t* out_ws, size_t out_stride);
+BN_KERNEL k_g1p_to_h_affine(const int32_t* in_ws, size_t in_stride, size_t u, int32_t* h_ws, size_t h_stride, uint8_t* status);
 BN_KERNEL k_field_op(int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out, uint8_t* status);
 BN_KERNEL k_gt_pow(const uint8_t* gt, const uint8_t* scalars, size_t n, uint8_t* out, uint8_t* status);
 BN_KERNEL k_fr_decode(const uint8_t* ids, size_t t, int32_t* x_ws, uint8_t* status);
@@ -83,7 +86,7 @@ __global__ void k_kd_assign(const uint32_t* rep, uint32_t n, uint32_t* kid, uint
 __global__ void __launch_bounds__(256) k_kd_propagate(const uint32_t* rep, uint32_t n, uint32_t u, uint32_t* kid, uint32_t* hist);
 __global__ void k_kd_hist(const uint32_t* kid, uint32_t n, uint32_t u, uint32_t* hist, int* bad);
 __global__ void __launch_bounds__(1024) k_scan_excl(const uint32_t* hist, uint32_t u, uint32_t* cursor);
-__global__ void k_kd_scatter(const uint32_t* kid, uint32_t n, uint32_t u, uint32_t* cursor, uint32_t* perm);
+__global__ void __launch_bounds__(256) k_kd_scatter(const uint32_t* kid, uint32_t n, uint32_t u, uint32_t* cursor, uint32_t* perm);
 BN_KERNEL k_g2_prepare(const uint8_t* pks, const uint32_t* keys, uint32_t u, int32_t* table, uint8_t* key_ok);
 BN_KERNEL k_g2_expand(const int32_t* raw, uint32_t u, int32_t* expanded);
 __global__ void k_prep_unsort(const uint8_t* is_one, const uint8_t* flags, const uint32_t* perm, uint32_t n, uint8_t* valid);

@@ -262,6 +262,12 @@ class Engine:
                                                       ctypes.c_size_t(len(dst)), psd, po))
         return o[:(n + 7) // 8].tobytes()
 
+    def aggregate_path_stats(self):
+        """(aggregate_verify calls served by per-key sums, calls served pair by pair)"""
+        o = (ctypes.c_uint64 * 2)()
+        self._chk(self._lib.blsbn254_aggregate_path_stats(self._ctx, o))
+        return int(o[0]), int(o[1])
+
     def set_rlc_group(self, group):
         """tuples per chunk of the repeated-key RLC path; 0 = automatic (16, raised when that saves a round of waves)"""
         self._chk(self._lib.blsbn254_set_rlc_group(self._ctx, ctypes.c_size_t(group)))

@@ -110,6 +110,13 @@ int blsbn254_aggregate_verify(blsbn254_ctx* ctx, const uint8_t* pks, const uint8
  * blsbn254_set_auto_prepare(ctx, 0) forces the exact path; blsbn254_path_stats counts the chunks each path served. */
 int blsbn254_set_auto_prepare(blsbn254_ctx* ctx, int on);
 int blsbn254_path_stats(blsbn254_ctx* ctx, uint64_t out[2] /* prepared, exact */);
+/* blsbn254_aggregate_verify over repeated keys (same rule: at most half of the n keys distinct, n >= 1024, auto-prepare on):
+ * by bilinearity in the first argument  prod_{i: pk_i = pk} e(H(msg_i), pk) = e(sum_i H(msg_i), pk)  -- exact, no randomness --
+ * the H(msg_i) of every distinct key are summed in G1 (n additions) and ONE Miller loop per distinct key runs
+ * (multi_miller_loop over u + 1 prepared terms, pairings.rs:808-857).  Same boolean; the Miller value differs from the product
+ * of the n per-pair values, which blsbn254_aggregate_partial keeps computing bit-exactly for the sharded API.
+ * out[0] = calls served by key sums, out[1] = calls served pair by pair. */
+int blsbn254_aggregate_path_stats(blsbn254_ctx* ctx, uint64_t out[2]);
 /* The explicit form: prepare u keys once (device-resident, owned by the handle, tied to ctx), then verify any number of
  * batches against them, naming the key of every tuple by its index (key_idx[i] < u, else BLSBN254_E_ARG).  A key that
  * does not decode, is the identity, is off the curve or outside the r-torsion makes its tuples invalid (bit cleared). */

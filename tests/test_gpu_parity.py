@@ -855,6 +855,39 @@ def test_aggregate_with_repeated_keys_prepared_path(eng, oracle, M, n, pool):
     eng.set_auto_prepare(True)
 
 
+@pytest.mark.parametrize("n,pool", [(1024, 1), (5000, 3), (40000, 2), (3000, 700)])
+def test_aggregate_verify_sums_per_key(eng, oracle, pyref, M, n, pool):
+    """aggregate_verify over repeated keys sums the H(msg_i) of every distinct key and runs ONE Miller loop per key
+    (bilinearity in the first argument; one to three levels of chunk sums here, keys of multiplicity 1 included): same
+    boolean as the pair-by-pair path on valid, tampered, wrong-signature and invalid-key batches."""
+    dst = M.DEFAULT_DST
+    sks = [synth.sk_of(k) for k in range(pool)]
+    pkp = eng.sk_to_pk_batch(b"".join(s.to_bytes(32, "big") for s in sks), pool)
+    pkp = [pkp[128 * k:128 * k + 128] for k in range(pool)]
+    msgs = [synth.msg_of(90000 + i) for i in range(n)]
+    # skewed multiplicities: key 0 takes every tuple whose index is not a multiple of 7, the others share the rest
+    kidx = [0 if (i % 7 or pool == 1) else 1 + (i // 7) % (pool - 1) for i in range(n)]
+    pks = b"".join(pkp[k] for k in kidx)
+    skb = b"".join(sks[k].to_bytes(32, "big") for k in kidx)
+    agg = eng.aggregate_sigs(eng.sign_batch(skb, msgs, dst), n)
+    g0, p0 = eng.aggregate_path_stats()
+    assert eng.aggregate_verify(pks, msgs, agg, dst) is True
+    bad = list(msgs); bad[n // 2] = b"tampered"
+    assert eng.aggregate_verify(pks, bad, agg, dst) is False
+    assert eng.aggregate_verify(pks, msgs, oracle.g1_add(agg, oracle.g1_generator()), dst) is False
+    assert eng.aggregate_verify(pks, msgs, IDENT1, dst) is False
+    assert eng.aggregate_verify(pks[:128 * (n - 1)] + synth.NON_SUBGROUP_PK, msgs, agg, dst) is False
+    g1, p1 = eng.aggregate_path_stats()
+    assert (g1 - g0, p1 - p0) == (5, 0)
+    eng.set_auto_prepare(False)                           # the pair-by-pair path agrees
+    try:
+        assert eng.aggregate_verify(pks, msgs, agg, dst) is True
+        assert eng.aggregate_verify(pks, bad, agg, dst) is False
+    finally:
+        eng.set_auto_prepare(True)
+    assert eng.aggregate_path_stats() == (g1, p1 + 2)
+
+
 def test_multi_miller_loop_over_prepared_keys(eng, oracle, pyref, M):
     """multi_miller_loop(&[(&G1Affine, &G2Prepared)]) with the G2 side prepared once (G2Prepared::from, pairings.rs:609-660,
     which panics in the reference: E6): same 384 bytes as the plain multi_miller_loop of the oracle; identity G1 terms are
