@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--tuples-per-gpu", dest="n", type=int, default=0,
                     help="tuples per GPU (default: 262144 at --gpus 1 = configs[1], 1048576 at --gpus N > 1 = configs[3])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-paths", action="store_true",
+                    help="skip the untimed exact_path / rlc_path legs (profiling runs: keeps rocprofv3's per-kernel averages to the timed path)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--all-on-device0", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -222,7 +224,7 @@ def run_rank(args):
             "algorithmic_fp_mul_per_verify": {"miller_variable_pair": core[0], "miller_fixed_pair_lines": core[1], "final_exp": core[2],
                                               "miller_shared_squarings": core[4], "dominant_kernel": alg_fp_mul},
         }
-        if world == 1 and prepared:
+        if world == 1 and prepared and not args.no_side_paths:
             # the same batch through the exact per-tuple path (what a batch of all-distinct keys takes), reported beside the
             # headline so that the number does not hinge on the workload's key pool; outside the timed region above
             eng.set_auto_prepare(False)
@@ -242,7 +244,7 @@ def run_rank(args):
                                  "kernel_ms": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in pe.items()},
                                  "roofline_frac_k_miller_verify": round((core[0] + core[1]) * FP_MUL_MADS * n / (mv_ms * 1e-3) / 1e12 / peak, 4),
                                  "note": "same batch with key de-duplication / preparation switched off: per-tuple G2 check + variable-Q Miller loop"}
-        if world == 1 and prepared:
+        if world == 1 and prepared and not args.no_side_paths:
             # the same batch through random-linear-combination batch verification: per-key chunks of 16
             # tuples checked as one virtual tuple each, failed chunks re-verified exactly; same bitmap (2^-64 per chunk).
             # Reported beside the headline, never as `value`: a verify here is no longer one pairing.

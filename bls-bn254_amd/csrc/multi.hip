@@ -127,6 +127,25 @@ int blsbn254_verify_batch_multi(blsbn254_multi* m, const uint8_t* pks, const uin
   return first_rc(m, rcs);
 }
 
+// blsbn254_verify_batch_rlc over all devices: every device draws its own seed (seed == NULL) or uses the caller's (tests)
+int blsbn254_verify_batch_rlc_multi(blsbn254_multi* m, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, const uint8_t* sigs,
+                                    size_t n, const uint8_t* dst, size_t dst_len, const uint8_t seed[32], uint8_t* bm) {
+  if (!m || !off || (n && (!pks || !sigs || !bm)) || (dst_len && !dst)) return BLSBN254_E_ARG;
+  if (n == 0) return 0;
+  const size_t G = m->ctx.size();
+  std::vector<int> rcs(G, 0);
+  std::vector<std::thread> th;
+  for (size_t g = 0; g < G; ++g) {
+    const size_t lo = shard_lo(n, g, G), hi = shard_lo(n, g + 1, G);
+    if (hi == lo) continue;
+    th.emplace_back([=, &rcs]() {
+      rcs[g] = blsbn254_verify_batch_rlc(m->ctx[g], pks + 128 * lo, msgs, off + lo, sigs + 64 * lo, hi - lo, dst, dst_len, seed, bm + lo / 8);
+    });
+  }
+  for (std::thread& t : th) t.join();
+  return first_rc(m, rcs);
+}
+
 int blsbn254_aggregate_verify_multi(blsbn254_multi* m, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,
                                     const uint8_t agg_sig[64], const uint8_t* dst, size_t dst_len, int* valid) {
   if (!m || !valid || !agg_sig || !off || (n && !pks) || (dst_len && !dst)) return BLSBN254_E_ARG;

@@ -554,6 +554,16 @@ class MultiEngine:
                                                         ctypes.c_size_t(len(dst)), po))
         return o[:(n + 7) // 8].tobytes()
 
+    def verify_batch_rlc(self, pks, msgs, sigs, dst=DEFAULT_DST, seed=None):
+        n = len(msgs)
+        data, off = pack_messages(msgs)
+        a, pa = _inbuf(pks, 128 * n); m, pm = _inbuf(data); s, ps = _inbuf(sigs, 64 * n); d, pd = _inbuf(dst)
+        sd, psd = (None, ctypes.cast(None, _u8p)) if seed is None else _inbuf(seed, 32)
+        o, po = _outbuf((n + 7) // 8)
+        self._chk(self._lib.blsbn254_verify_batch_rlc_multi(self._m, pa, pm, off.ctypes.data_as(_u64p), ps, ctypes.c_size_t(n), pd,
+                                                            ctypes.c_size_t(len(dst)), psd, po))
+        return o[:(n + 7) // 8].tobytes()
+
     def aggregate_verify(self, pks, msgs, agg_sig, dst=DEFAULT_DST):
         n = len(msgs)
         data, off = pack_messages(msgs)

@@ -300,6 +300,11 @@ const char* blsbn254_multi_last_error(blsbn254_multi* m);
  * copies its slice of the bitmap into valid_bitmap (a host gather of disjoint slices). */
 int blsbn254_verify_batch_multi(blsbn254_multi* m, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off,
                                 const uint8_t* sigs, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* valid_bitmap);
+/* blsbn254_verify_batch_rlc over all devices of m (each device verifies its contiguous shard with its own chunks and weights):
+ * same bitmap as blsbn254_verify_batch_multi. */
+int blsbn254_verify_batch_rlc_multi(blsbn254_multi* m, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off,
+                                    const uint8_t* sigs, size_t n, const uint8_t* dst, size_t dst_len,
+                                    const uint8_t seed[32], uint8_t* valid_bitmap);
 /* blsbn254_aggregate_verify over all devices of m: per-device blsbn254_aggregate_partial, the 384-byte partials are
  * gathered on the host, one blsbn254_aggregate_finish on the first device. */
 int blsbn254_aggregate_verify_multi(blsbn254_multi* m, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n,

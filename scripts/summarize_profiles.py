@@ -38,7 +38,7 @@ t = out["kernels"][dom]["hbm_bytes_per_launch"]
 bj["roofline"]["traffic"] = t
 bj["roofline"]["traffic_note"] = ("PMC FETCH_SIZE/WRITE_SIZE of the same kernel at the same batch size (profiles/%s_traffic.json): %.1f KB per tuple "
                                   "against ~0.6 KB algorithmic (sig 64 B, H 108 B, f out 432 B; line tables from cache)" % (TAG, t / 262144 / 1024.0))
-for extra in ("bench_exact.json", "configs.json", "valu_peak.json"):
+for extra in ("bench_exact.json", "configs.json", "valu_peak.json", "rlc.json", "rlc_1m.json"):
     src = os.path.join(SRC, extra)
     if os.path.exists(src):
         txt = open(src).read()

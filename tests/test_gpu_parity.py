@@ -545,6 +545,51 @@ def test_verify_batch_rlc_dev_full_size(eng, oracle, M):
     assert bytes(t_b.cpu().numpy()) == want
 
 
+def test_verify_batch_rlc_edge_cases(eng, oracle, pyref, M, monkeypatch):
+    """Repeated-key RLC path on awkward batches: a key none of whose tuples is eligible (every signature off the curve), a key
+    outside the subgroup carrying many tuples, the distinct / repeated switch-over (n = 2 u), identity signatures, and a batch
+    beyond one launch chunk (chunk forced to 64: every chunk de-duplicates and weighs on its own)."""
+    dst = M.DEFAULT_DST
+    sks = [synth.sk_of(k) for k in range(8)]
+    pkp = [oracle.sk_to_pk(s) for s in sks]
+    n = 96
+    msgs = [synth.msg_of(500 + i) for i in range(n)]
+    kidx = [i % 4 for i in range(n)]
+    sigs = [oracle.sign(sks[k], m, dst) for k, m in zip(kidx, msgs)]
+    pks = [pkp[k] for k in kidx]
+    exp = [True] * n
+    for i in range(n):
+        if kidx[i] == 1:                                   # every signature of key 1: off the curve
+            sigs[i] = sigs[i][:32] + (int.from_bytes(sigs[i][32:], "big") ^ 1).to_bytes(32, "big"); exp[i] = False
+        elif kidx[i] == 2:                                 # key 2 replaced by a point outside the subgroup
+            pks[i] = synth.NON_SUBGROUP_PK; exp[i] = False
+        elif i in (3, 7):                                  # identity signatures under key 3
+            sigs[i] = IDENT1; exp[i] = False
+    want = synth.bitmap_of(exp)
+    for group in (0, 2, 5):
+        eng.set_rlc_group(group)
+        assert eng.verify_batch_rlc(b"".join(pks), msgs, b"".join(sigs), dst) == want
+    eng.set_rlc_group(0)
+    assert eng.verify_batch(b"".join(pks), msgs, b"".join(sigs), dst) == want
+    # switch-over: 8 distinct keys; 16 tuples take the chunked path, 15 the distinct-key variant -- same bitmaps
+    for m in (15, 16):
+        p2, m2, s2, e2 = synth.make_batch(oracle, m, dst, pool=8, invalid_every=4, uniq=m)
+        before = eng.rlc_stats()
+        assert eng.verify_batch_rlc(p2, m2, s2, dst) == synth.bitmap_of(e2)
+        after = eng.rlc_stats()
+        assert (after["chunked_tuples"] - before["chunked_tuples"], after["distinct_key_tuples"] - before["distinct_key_tuples"]) == ((16, 0) if m == 16 else (0, 15))
+    monkeypatch.setenv("BLSBN254_CHUNK_LANES", "64")
+    e = M.Engine(0)
+    try:
+        n = 64 * 3 + 17
+        p3, m3, s3, e3 = synth.make_batch(oracle, n, dst, invalid_every=5, uniq=16)
+        assert e.verify_batch_rlc(p3, m3, s3, dst) == synth.bitmap_of(e3)
+        st = e.rlc_stats()                       # the 17-tuple tail holds 9 distinct keys: it takes the exact path
+        assert st["chunked_tuples"] == 192 and st["chunked_tuples"] + st["distinct_key_tuples"] == n
+    finally:
+        e.close()
+
+
 def test_chunked_entry_points(oracle, pyref, M, monkeypatch):
     """Batches larger than the per-launch chunk (4 Mi tuples in production; forced to 64 here through the
     BLSBN254_CHUNK_LANES test knob) are processed chunk by chunk: same results as the one-launch path."""

@@ -21,7 +21,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _verify_worker(rank, world, port, n, outdir):
+def _verify_worker(rank, world, port, n, outdir, rlc=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -45,7 +45,8 @@ def _verify_worker(rank, world, port, n, outdir):
         t_off = torch.from_numpy(off.astype(np.int64)).to(dev)
         t_bm = torch.zeros((m + 7) // 8, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
-        eng.verify_batch_dev(t_pk.data_ptr(), t_ms.data_ptr(), t_off.data_ptr(), t_sg.data_ptr(), m, t_bm.data_ptr(), dst)
+        fn = eng.verify_batch_rlc_dev if rlc else eng.verify_batch_dev       # same bitmap either way
+        fn(t_pk.data_ptr(), t_ms.data_ptr(), t_off.data_ptr(), t_sg.data_ptr(), m, t_bm.data_ptr(), dst)
         eng.synchronize()
         return t_bm.cpu()          # gloo reduces host tensors
     words = sharded.verify_batch_sharded(verify_local, n, rank, world, dist, torch, torch.device("cpu"))
@@ -87,10 +88,10 @@ def _agg_worker(rank, world, port, n, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [37, 256])
-def test_world2_verify_batch_sharded_with_engine(tmp_path, oracle, n):
+@pytest.mark.parametrize("n,rlc", [(37, False), (256, False), (256, True)])
+def test_world2_verify_batch_sharded_with_engine(tmp_path, oracle, n, rlc):
     import torch.multiprocessing as mp
-    mp.spawn(_verify_worker, args=(2, _free_port(), n, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_verify_worker, args=(2, _free_port(), n, str(tmp_path), rlc), nprocs=2, join=True)
     pks, msgs, sigs, exp = synth.make_batch(oracle, n, b"TEST_DST", invalid_every=3, uniq=12)
     want = oracle.verify_batch(pks, msgs, sigs, b"TEST_DST", nthreads=4)
     assert want == synth.bitmap_of(exp)
@@ -119,6 +120,7 @@ def test_c_abi_multi_device_equals_single(oracle):
             assert want == synth.bitmap_of(exp)
             assert me.verify_batch(pks, msgs, sigs, dst) == want
             assert me3.verify_batch(pks, msgs, sigs, dst) == want
+            assert me.verify_batch_rlc(pks, msgs, sigs, dst) == want and me3.verify_batch_rlc(pks, msgs, sigs, dst, seed=bytes(32)) == want
         assert me.verify_batch(b"", [], b"", dst) == b""
         n = 11
         sks = [synth.sk_of(k) for k in range(n)]
