@@ -176,6 +176,24 @@ pub fn verify_batch(pks: &[[u8; 128]], msgs: &[&[u8]], sigs: &[[u8; 64]], dst: &
     bits(&bm, n)
 }
 
+/// Batch verification by random linear combination: the same answers as `verify_batch` (an invalid chunk of 16 tuples passes
+/// with probability about 2^-64), several times faster on batches that repeat public keys.  The weights are drawn inside the
+/// library (OS randomness, after the batch is fixed).
+pub fn verify_batch_rlc(pks: &[[u8; 128]], msgs: &[&[u8]], sigs: &[[u8; 64]], dst: &[u8]) -> Vec<bool> {
+    assert!(pks.len() == msgs.len() && msgs.len() == sigs.len());
+    let n = pks.len();
+    let (data, off) = pack(msgs);
+    let pk: Vec<u8> = pks.iter().flatten().copied().collect();
+    let sg: Vec<u8> = sigs.iter().flatten().copied().collect();
+    let mut bm = vec![0u8; (n + 7) / 8];
+    with_ctx(|c| check(unsafe {
+        ffi::blsbn254_verify_batch_rlc(c, pk.as_ptr(), data.as_ptr(), off.as_ptr(), sg.as_ptr(), n, dst.as_ptr(), dst.len(),
+                                       std::ptr::null(), bm.as_mut_ptr())
+    }))
+    .expect("per-tuple failures are reported in the bitmap");
+    bits(&bm, n)
+}
+
 /// CoreAggregateVerify: one aggregate signature over `n` (public key, message) pairs.
 pub fn aggregate_verify(pks: &[[u8; 128]], msgs: &[&[u8]], agg_sig: &[u8; 64], dst: &[u8]) -> bool {
     assert_eq!(pks.len(), msgs.len());

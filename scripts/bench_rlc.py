@@ -1,6 +1,6 @@
 """RLC batch verification vs the exact path at the bench workload: inputs resident in HBM (device entry points), kernel
 time by HIP events and wall time per step; three invalid rates, several chunk sizes.
-Usage: python scripts/bench_rlc.py [n] [groups, comma separated]  ->  JSON on stdout"""
+Usage: python scripts/bench_rlc.py [n] [groups, comma separated; 0 = automatic] [contexts in flight, comma separated]  ->  JSON on stdout"""
 import json, os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
@@ -11,6 +11,7 @@ from tests import synth
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 groups = [int(g) for g in sys.argv[2].split(",")] if len(sys.argv) > 2 else [16]
+pipeline = [int(k) for k in sys.argv[3].split(",")] if len(sys.argv) > 3 else []      # contexts in flight, e.g. 2,3
 e = M.Engine(0); dst = M.DEFAULT_DST
 dev = torch.device("cuda", 0)
 out = {"n": n, "pool": 1024}
@@ -51,6 +52,34 @@ for name, inv in (("1/64 invalid (bench workload: invalid tuples on 16 keys)", 6
         if g is not None:
             res[label]["chunks_per_step"] = (s1["chunks"] - s0["chunks"]) // reps
             res[label]["fallback_tuples_per_step"] = (s1["fallback_tuples"] - s0["fallback_tuples"]) // reps
+    # Throughput with several batches in flight: K contexts (own stream + workspace each) driven by K host threads.  A single
+    # RLC call is latency-bound in its chunk round (a quarter of the SIMDs busy); with two or three calls in flight the
+    # rounds of one overlap the hashing / weighting of another.  The exact path fills the chip by itself (shown for contrast).
+    if pipeline:
+        import threading
+        for label, rlc in (("exact", False), ("rlc_auto", True)):
+            for K in pipeline:
+                engs = [e] + [M.Engine(0) for _ in range(K - 1)]
+                bms = [torch.zeros((n + 7) // 8, dtype=torch.uint8, device=dev) for _ in range(K)]
+                torch.cuda.synchronize()
+                reps = 6
+
+                def work(j, count):
+                    fn = engs[j].verify_batch_rlc_dev if rlc else engs[j].verify_batch_dev
+                    for _ in range(count):
+                        fn(t_pk.data_ptr(), t_ms.data_ptr(), t_off.data_ptr(), t_sg.data_ptr(), n, bms[j].data_ptr(), dst)
+                        engs[j].synchronize()
+                for warm in (1, reps):
+                    th = [threading.Thread(target=work, args=(j, warm)) for j in range(K)]
+                    t = time.perf_counter()
+                    for x in th: x.start()
+                    for x in th: x.join()
+                    dt = time.perf_counter() - t
+                for j in range(K):
+                    assert bytes(bms[j].cpu().numpy()) == want, (label, K, j)
+                res[label]["in_flight_%d" % K] = {"ms_per_batch": round(dt / (K * reps) * 1e3, 2), "verifies_per_s": round(n * K * reps / dt)}
+                for x in engs[1:]:
+                    x.close()
     out[name] = res
 e.set_rlc_group(0)
 print(json.dumps(out, indent=1))

@@ -13,7 +13,7 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 timeout -k 10 400 python3 bench.py --steps 10 --warmup 2 > $O/bench.json 2> $O/bench.err &&
 BLSBN254_AUTO_PREPARE=0 timeout -k 10 400 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_exact.json 2> $O/bench_exact.err &&
 timeout -k 10 300 python3 scripts/bench_configs.py > $O/configs.json 2> $O/configs.err &&
-timeout -k 10 300 python3 scripts/bench_rlc.py 262144 8,0 > $O/rlc.json 2> $O/rlc.err &&
+timeout -k 10 300 python3 scripts/bench_rlc.py 262144 8,0 2,3 > $O/rlc.json 2> $O/rlc.err &&
 timeout -k 10 300 python3 scripts/bench_rlc.py 1048576 0 > $O/rlc_1m.json 2> $O/rlc_1m.err &&
 timeout -k 10 200 ./bench_micro/valu_peak > $O/valu_peak.json 2> $O/valu_peak.err
 echo rc=$?
