@@ -1284,11 +1284,20 @@ static int aggregate_verify_grouped(blsbn254_ctx* c, const uint8_t* pks, const u
   LAUNCH(c, "g1_to_ws", k_g1_to_ws, 1, (const uint8_t*)c->in_b.p, h2, u, np, (uint8_t*)(d_ok + 1));
   LAUNCH(c, "iota", k_iota_u32, np, kid2, (uint32_t)np);
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-  LAUNCH(c, "miller_hpk2p", k_miller_hpk2p, n_lanes, (const int32_t*)h2, np, (const uint32_t*)kid2, (const int32_t*)c->prep_raw.p, (const uint8_t*)c->prep_ok.p, np,
-         (int32_t*)c->f_ws.p, n_lanes, (uint8_t*)c->flags.p, (const uint8_t*)st);
+  // few pairs: the launch is the latency of one wave, so one pair per lane (no shared f^2, shorter chain); else two per lane
+  const bool one_per_lane = np * 2 <= c->lanes_per_round;
+  const size_t f_cnt = one_per_lane ? np : n_lanes;
+  HIPCHK(c, c->f_ws.reserve(f_cnt * 108 * 4));
+  if (one_per_lane) {
+    LAUNCH(c, "miller_hpk1p", k_miller_hpk1p, np, (const int32_t*)h2, np, (const uint32_t*)kid2, (const int32_t*)c->prep_raw.p, (const uint8_t*)c->prep_ok.p, np,
+           (int32_t*)c->f_ws.p, np, (uint8_t*)c->flags.p, (const uint8_t*)st);
+  } else {
+    LAUNCH(c, "miller_hpk2p", k_miller_hpk2p, n_lanes, (const int32_t*)h2, np, (const uint32_t*)kid2, (const int32_t*)c->prep_raw.p, (const uint8_t*)c->prep_ok.p, np,
+           (int32_t*)c->f_ws.p, n_lanes, (uint8_t*)c->flags.p, (const uint8_t*)st);
+  }
   LAUNCH(c, "and_reduce", k_and_reduce, u, (const uint8_t*)c->flags.p, (const uint8_t*)c->flags.p, u, d_ok);
   int32_t* res; size_t rs;
-  rc = fp12_tree(c, (int32_t*)c->f_ws.p, n_lanes, n_lanes, &res, &rs);
+  rc = fp12_tree(c, (int32_t*)c->f_ws.p, f_cnt, f_cnt, &res, &rs);
   if (rc) return rc;
   rc = run_final_exp(c, res, 1, rs, 3, nullptr, nullptr, nullptr, nullptr, d_ok + 4);
   if (rc) return rc;

@@ -32,6 +32,8 @@ BN_KERNEL k_miller_hpk(const int32_t* h_ws, const uint8_t* pks, size_t n, int32_
 BN_KERNEL k_miller_hpk2(const int32_t* h_ws, const uint8_t* pks, size_t n, int32_t* q_ws, int32_t* f_ws, size_t f_stride, uint8_t* flags);
 BN_KERNEL k_miller_hpk2p(const int32_t* h_ws, size_t h_stride, const uint32_t* kid, const int32_t* table, const uint8_t* key_ok, size_t n,
                          int32_t* f_ws, size_t f_stride, uint8_t* flags, const uint8_t* skip);
+BN_KERNEL k_miller_hpk1p(const int32_t* h_ws, size_t h_stride, const uint32_t* kid, const int32_t* table, const uint8_t* key_ok, size_t n,
+                         int32_t* f_ws, size_t f_stride, uint8_t* flags, const uint8_t* skip);
 BN_KERNEL k_g1_to_ws_batch(const uint8_t* g1, size_t n, int32_t* h_ws, uint8_t* status);
 BN_KERNEL k_g1_to_ws(const uint8_t* g1, int32_t* h_ws, size_t slot, size_t stride, uint8_t* ok);
 BN_KERNEL k_miller_verify(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n, int32_t* f_ws, uint8_t* flags);

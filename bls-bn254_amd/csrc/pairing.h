@@ -633,6 +633,32 @@ BN_FUNC Fp12 miller_loop_prepared(const Ws& inv, const Ws& ktab_in) {
   return f;
 }
 
+// One pair per lane with a prepared key: f = ML(H, Q), the line triples of Q read from its raw table (88 x 54 limbs).  More work
+// per pair than the two-pairs-per-lane loop below (f^2 is not shared) but the shortest chain per lane: used when a launch has so
+// few pairs that it is bound by the latency of one wave (aggregate verify over a handful of distinct keys).  hh (LDS): H.x, H.y.
+BN_FUNC Fp12 miller_loop_1prepared(const Ws& hh_in, const Ws& ta_in) {
+  Fp12 f = fp12_one();
+  Ws hh = hh_in, ta = ta_in;
+  int ti = 0;
+  for (int j = bnc::ATE_NAF_LEN - 2; j >= 0; --j) {
+    f = fp12_sqr(f);
+    BN_OPAQUE(ta); BN_OPAQUE(hh);
+    f = ell(f, line_load_limbs(ws_at(ta, 54 * (size_t)ti)), fp_load_mem(hh), fp_load_mem(ws_at(hh, 9)));
+    ++ti;
+    if (ate_naf_digit(j) != 0) {
+      BN_OPAQUE(ta); BN_OPAQUE(hh);
+      f = ell(f, line_load_limbs(ws_at(ta, 54 * (size_t)ti)), fp_load_mem(hh), fp_load_mem(ws_at(hh, 9)));
+      ++ti;
+    }
+  }
+  for (int e = 0; e < 2; ++e) {
+    BN_OPAQUE(ta); BN_OPAQUE(hh);
+    f = ell(f, line_load_limbs(ws_at(ta, 54 * (size_t)ti)), fp_load_mem(hh), fp_load_mem(ws_at(hh, 9)));
+    ++ti;
+  }
+  return f;
+}
+
 // Two pairs per lane, BOTH with prepared keys (aggregate verify over a batch that repeats few public keys): f = ML(Ha, Qa) *
 // ML(Hb, Qb) with the line triples of Qa and Qb read from their keys' raw tables (88 x 54 limbs each, k_g2_prepare) -- one
 // squaring of f and one two-line product per loop digit, no point arithmetic.  hh (LDS): Ha.x, Ha.y, Hb.x, Hb.y.

@@ -900,10 +900,11 @@ def test_aggregate_with_repeated_keys_prepared_path(eng, oracle, M, n, pool):
     eng.set_auto_prepare(True)
 
 
-@pytest.mark.parametrize("n,pool", [(1024, 1), (5000, 3), (40000, 2), (3000, 700)])
+@pytest.mark.parametrize("n,pool", [(1024, 1), (5000, 3), (40000, 2), (3000, 700), (66200, 33050)])      # the last: two pairs per lane
 def test_aggregate_verify_sums_per_key(eng, oracle, pyref, M, n, pool):
     """aggregate_verify over repeated keys sums the H(msg_i) of every distinct key and runs ONE Miller loop per key
-    (bilinearity in the first argument; one to three levels of chunk sums here, keys of multiplicity 1 included): same
+    (bilinearity in the first argument; one to three levels of chunk sums here, keys of multiplicity 1 included; one pair per
+    lane while the launch is latency-bound, two per lane beyond 32768 pairs): same
     boolean as the pair-by-pair path on valid, tampered, wrong-signature and invalid-key batches."""
     dst = M.DEFAULT_DST
     sks = [synth.sk_of(k) for k in range(pool)]
@@ -911,7 +912,8 @@ def test_aggregate_verify_sums_per_key(eng, oracle, pyref, M, n, pool):
     pkp = [pkp[128 * k:128 * k + 128] for k in range(pool)]
     msgs = [synth.msg_of(90000 + i) for i in range(n)]
     # skewed multiplicities: key 0 takes every tuple whose index is not a multiple of 7, the others share the rest
-    kidx = [0 if (i % 7 or pool == 1) else 1 + (i // 7) % (pool - 1) for i in range(n)]
+    # (the many-key case spreads evenly: two tuples per key, 33051 pairs)
+    kidx = [i % pool if pool > 1000 else 0 if (i % 7 or pool == 1) else 1 + (i // 7) % (pool - 1) for i in range(n)]
     pks = b"".join(pkp[k] for k in kidx)
     skb = b"".join(sks[k].to_bytes(32, "big") for k in kidx)
     agg = eng.aggregate_sigs(eng.sign_batch(skb, msgs, dst), n)
