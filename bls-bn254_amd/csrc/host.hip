@@ -56,6 +56,9 @@ struct blsbn254_ctx {
   uint64_t stat_prepared_chunks = 0, stat_exact_chunks = 0, stat_grouped_aggregates = 0, stat_pairwise_aggregates = 0;
   DevBuf q_ws;           // decoded public keys of the two-pairs-per-lane Miller kernel, 72 x lanes limbs
   DevBuf th_x, th_num, th_den, th_glv, th_part, th_part2;   // threshold combine: ids, partial products, GLV halves, window sums
+  DevBuf fe_wide_one;    // validity bytes of the wave-per-tuple final exponentiation (mode 0)
+  bool wide_fe = true;               // BLSBN254_WIDE_FE=0 disables the wave-per-tuple hard part
+  size_t wide_fe_max = 4096;         // ... used for launches of at most this many tuples (BLSBN254_WIDE_FE_MAX)
   DevBuf fe_slots;       // the ten named powers of the t -> t^x addition chain, 10 x 108 x n limbs
   uint8_t dst_host[256];  // the (pre-hashed if oversize) DST currently resident in `dst`, and its length; -1 = none
   int dst_host_len = -1;
@@ -81,6 +84,10 @@ struct ProfScope {
 };
 #define LAUNCH(ctx, name, kernel, n, ...) do { ProfScope ps_(ctx, name); \
     hipLaunchKernelGGL(kernel, dim3(nblocks(n)), dim3(256), 0, (ctx)->stream, __VA_ARGS__); } while (0); HIPCHK(ctx, hipGetLastError())
+
+// one workgroup of 64 lanes (one wave) per element: the wave-per-tuple kernels (wide.h)
+#define LAUNCH_WIDE(ctx, name, kernel, n, ...) do { ProfScope ps_(ctx, name); \
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(n)), dim3(64), 0, (ctx)->stream, __VA_ARGS__); } while (0); HIPCHK(ctx, hipGetLastError())
 
 // the same on the context's second stream (events recorded there)
 struct ProfScope2 {
@@ -143,6 +150,8 @@ int blsbn254_ctx_create(int device, blsbn254_ctx** out) {
   if (const char* e = std::getenv("BLSBN254_AUTO_PREPARE")) c->auto_prepare = std::atoi(e) != 0;
   if (const char* e = std::getenv("BLSBN254_RLC_GROUP")) { long v = std::atol(e); if (v >= 2 && v <= 4096) { c->rlc_group = (size_t)v; c->rlc_group_auto = false; } }
   c->lanes_per_round = (size_t)prop.multiProcessorCount * 256;
+  if (const char* e = std::getenv("BLSBN254_WIDE_FE")) c->wide_fe = std::atoi(e) != 0;
+  if (const char* e = std::getenv("BLSBN254_WIDE_FE_MAX")) { long v = std::atol(e); if (v >= 0 && v <= (1 << 20)) c->wide_fe_max = (size_t)v; }
   *out = c;
   return 0;
 }
@@ -154,7 +163,7 @@ void blsbn254_ctx_destroy(blsbn254_ctx* c) {
   DevBuf* bufs[] = {&c->in_a, &c->in_b, &c->in_c, &c->in_off, &c->dst, &c->h_ws, &c->f_ws, &c->f_ws2, &c->flags, &c->sub_ok, &c->status, &c->status_all, &c->bitmap, &c->out, &c->scalars, &c->misc};
   for (DevBuf* b : bufs) b->release();
   for (DevBuf& b : c->fe) b.release();
-  c->fe_slots.release();
+  c->fe_slots.release(); c->fe_wide_one.release();
   { DevBuf* tb[] = {&c->th_x, &c->th_num, &c->th_den, &c->th_glv, &c->th_part, &c->th_part2, &c->q_ws}; for (DevBuf* b : tb) b->release(); }
   { DevBuf* rb[] = {&c->rlc_a2, &c->rlc_a, &c->rlc_b, &c->rlc_elig, &c->rlc_f2, &c->rlc_bytes, &c->rlc_neg, &c->rlc_ok, &c->rlc_idx, &c->rlc_cpk, &c->rlc_csig, &c->rlc_ch, &c->rlc_csub, &c->rlc_cbm};
     for (DevBuf* b : rb) b->release(); }
@@ -311,6 +320,15 @@ static int run_final_exp(blsbn254_ctx* c, int32_t* f, size_t n, size_t stride, i
   int32_t *X = (int32_t*)c->fe[0].p, *A = (int32_t*)c->fe[1].p, *B = (int32_t*)c->fe[2].p, *C = (int32_t*)c->fe[3].p,
           *B2 = (int32_t*)c->fe[4].p, *D = (int32_t*)c->fe[5].p;
   LAUNCH(c, "fe_easy", k_fe_easy, n, (const int32_t*)f, f, n, stride);                       // t (in place)
+  // Few tuples: the lane-per-tuple kernels below would be the latency of one lane's chain (4.5 ms for any n <= 65536); the hard
+  // part runs with one WAVE per tuple instead (k_fe_wide.hip): ~0.6 ms per round of CUs x 16 tuples.  Same values.
+  if (c->wide_fe && n <= c->wide_fe_max) {
+    uint8_t* one = nullptr;
+    if (mode == 0) { HIPCHK(c, c->fe_wide_one.reserve(n)); one = (uint8_t*)c->fe_wide_one.p; }
+    LAUNCH_WIDE(c, "fe_hard_wide", k_fe_hard_wide, n, (const int32_t*)f, n, stride, flags, sub_ok, one, d_gt, d_is_one, mode);
+    if (mode == 0) { LAUNCH(c, "pack_bitmap", k_pack_bitmap, n, (const uint8_t*)one, n, d_bitmap); }
+    return 0;
+  }
   // t^x three times; the glue steps fe_h1 / fe_h2 are computed by the first two launches themselves (k_fe_expx_tail.hip)
   LAUNCH(c, "fe_expx_h1", k_fe_expx_h1, n, (const int32_t*)f, S, n, stride, A, B);
   LAUNCH(c, "fe_expx_h2", k_fe_expx_h2, n, (const int32_t*)B, S, n, stride, B, C, B2, D);
@@ -537,8 +555,13 @@ static int verify_prepared_dev(blsbn254_ctx* c, const int32_t* table, const uint
   HIPCHK(c, hipGetLastError());
   LAUNCH(c, "kd_scatter", k_kd_scatter, n, d_kid, (uint32_t)n, (uint32_t)u, cursor, perm);
   if (join) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-  LAUNCH(c, "miller_prepared", k_miller_prepared, n, (const uint32_t*)perm, d_kid, d_sigs, (const int32_t*)c->h_ws.p, n, table, key_ok, n,
-         (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
+  if (c->wide_fe && n <= c->wide_fe_max) {            // few tuples: one wave per tuple (k_miller_wide.hip), same values
+    LAUNCH_WIDE(c, "miller_wide_prepared", k_miller_wide_prepared, n, (const uint32_t*)perm, d_kid, d_sigs, (const int32_t*)c->h_ws.p, n, table, key_ok, n,
+                (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
+  } else {
+    LAUNCH(c, "miller_prepared", k_miller_prepared, n, (const uint32_t*)perm, d_kid, d_sigs, (const int32_t*)c->h_ws.p, n, table, key_ok, n,
+           (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
+  }
   int rc = run_final_exp(c, (int32_t*)c->f_ws.p, n, n, 4, nullptr, nullptr, nullptr, (uint8_t*)c->prep_isone.p, nullptr);
   if (rc) return rc;
   LAUNCH(c, "prep_unsort", k_prep_unsort, n, (const uint8_t*)c->prep_isone.p, (const uint8_t*)c->flags.p, (const uint32_t*)perm, (uint32_t)n, (uint8_t*)c->prep_valid.p);
@@ -579,11 +602,14 @@ static int verify_chunk_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t
   // Few distinct keys (a validator set signing many messages): every distinct key is validated and turned into its line
   // table ONCE (G2Prepared), beside hash-to-G1, and the tuples run the table-only Miller loop in key-sorted order.
   // Same bitmap as the exact per-tuple path below, which batches of mostly distinct keys keep taking.
-  if (c->auto_prepare && n >= 1024) {
+  // Small chunks (at most wide_fe_max tuples) take it whatever their keys: with tables, the Miller loop and the final
+  // exponentiation can run one WAVE per tuple (k_miller_wide.hip, k_fe_wide.hip) instead of at the latency of one lane.
+  const bool small = c->wide_fe && n <= c->wide_fe_max;
+  if (c->auto_prepare && (n >= 1024 || small)) {
     size_t u = 0;
     int rc = dedup_keys(c, d_pks, n, &u);
     if (rc) return rc;
-    if (u * 2 <= n && u <= PREP_MAX_KEYS) {
+    if ((u * 2 <= n || small) && u <= PREP_MAX_KEYS) {
       HIPCHK(c, c->prep_table.reserve(u * PREP_KEY_LIMBS * 4)); HIPCHK(c, c->prep_ok.reserve(u));
       rc = prepare_keys_async(c, d_pks, (const uint32_t*)c->kd_keys.p, u, (int32_t*)c->prep_table.p, (uint8_t*)c->prep_ok.p);
       if (rc) return rc;
@@ -703,13 +729,21 @@ int blsbn254_multi_miller_loop_prepared(blsbn254_ctx* c, const blsbn254_g2prepar
   int rc = first_bad(c, (const uint8_t*)c->status.p, n, 1, 1, &bad);
   if (rc) return rc;
   if (bad >= 0) return BLSBN254_ERR_G1;
-  LAUNCH(c, "miller_hpk2p", k_miller_hpk2p, n_lanes, (const int32_t*)c->h_ws.p, n, (const uint32_t*)c->kd_kid.p, (const int32_t*)keys->raw.p,
-         (const uint8_t*)keys->ok.p, n, (int32_t*)c->f_ws.p, n_lanes, (uint8_t*)c->flags.p, (const uint8_t*)c->status.p);
+  const bool wide = c->wide_fe && n <= c->wide_fe_max;       // few pairs: one wave per pair, product of n values instead of n / 2
+  const size_t f_cnt = wide ? n : n_lanes;
+  if (wide) {
+    HIPCHK(c, c->f_ws.reserve(n * 108 * 4));
+    LAUNCH_WIDE(c, "miller_wide_1p", k_miller_wide_1p, n, (const int32_t*)c->h_ws.p, n, (const uint32_t*)c->kd_kid.p, (const int32_t*)keys->raw.p,
+                (const uint8_t*)keys->ok.p, n, (int32_t*)c->f_ws.p, n, (uint8_t*)c->flags.p, (const uint8_t*)c->status.p);
+  } else {
+    LAUNCH(c, "miller_hpk2p", k_miller_hpk2p, n_lanes, (const int32_t*)c->h_ws.p, n, (const uint32_t*)c->kd_kid.p, (const int32_t*)keys->raw.p,
+           (const uint8_t*)keys->ok.p, n, (int32_t*)c->f_ws.p, n_lanes, (uint8_t*)c->flags.p, (const uint8_t*)c->status.p);
+  }
   rc = first_bad(c, (const uint8_t*)c->flags.p, n, 1, 1, &bad);
   if (rc) return rc;
   if (bad >= 0) return BLSBN254_ERR_G2;
   int32_t* res; size_t rs;
-  rc = fp12_tree(c, (int32_t*)c->f_ws.p, n_lanes, n_lanes, &res, &rs);
+  rc = fp12_tree(c, (int32_t*)c->f_ws.p, f_cnt, f_cnt, &res, &rs);
   if (rc) return rc;
   LAUNCH(c, "fp12_to_bytes", k_fp12_to_bytes, 1, (const int32_t*)res, (size_t)1, rs, (uint8_t*)c->out.p);
   HIPCHK(c, hipMemcpyAsync(ml_out, c->out.p, 384, hipMemcpyDeviceToHost, c->stream));
@@ -789,8 +823,13 @@ static int draw_seed(blsbn254_ctx* c, uint8_t out[32]) {
 static int prepared_round(blsbn254_ctx* c, const uint32_t* perm, const uint32_t* kid, const uint8_t* sigs, const int32_t* h_ws, size_t h_stride,
                           size_t cnt, uint8_t* d_isone) {
   HIPCHK(c, c->f_ws.reserve(cnt * 108 * 4)); HIPCHK(c, c->flags.reserve(cnt));
-  LAUNCH(c, "miller_prepared", k_miller_prepared, cnt, perm, kid, sigs, h_ws, h_stride, (const int32_t*)c->prep_table.p, (const uint8_t*)c->prep_ok.p, cnt,
-         (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
+  if (c->wide_fe && cnt <= c->wide_fe_max) {
+    LAUNCH_WIDE(c, "miller_wide_prepared", k_miller_wide_prepared, cnt, perm, kid, sigs, h_ws, h_stride, (const int32_t*)c->prep_table.p, (const uint8_t*)c->prep_ok.p, cnt,
+                (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
+  } else {
+    LAUNCH(c, "miller_prepared", k_miller_prepared, cnt, perm, kid, sigs, h_ws, h_stride, (const int32_t*)c->prep_table.p, (const uint8_t*)c->prep_ok.p, cnt,
+           (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
+  }
   return run_final_exp(c, (int32_t*)c->f_ws.p, cnt, cnt, 4, nullptr, nullptr, nullptr, d_isone, nullptr);
 }
 // n <= ctx->chunk tuples, everything device-resident; d_seed = 32 bytes in device memory.  *took = 0 when the keys do not repeat
@@ -1217,7 +1256,8 @@ static int aggregate_verify_grouped(blsbn254_ctx* c, const uint8_t* pks, const u
   size_t u = 0;
   rc = dedup_keys(c, (const uint8_t*)c->in_a.p, n, &u);
   if (rc) return rc;
-  if (!(u * 2 <= n && u + 1 <= PREP_MAX_KEYS)) return 0;
+  const bool small = c->wide_fe && n + 1 <= c->wide_fe_max;       // few pairs: from tables, one wave per pair, whatever the keys
+  if (!((u * 2 <= n || small) && u + 1 <= PREP_MAX_KEYS)) return 0;
   *took = true;
   const size_t G = AGG_SUM_GROUP, np = u + 1, n_lanes = (np + 1) / 2;
   const uint32_t n32 = (uint32_t)n, u32 = (uint32_t)u, G32 = (uint32_t)G;
@@ -1288,7 +1328,10 @@ static int aggregate_verify_grouped(blsbn254_ctx* c, const uint8_t* pks, const u
   const bool one_per_lane = np * 2 <= c->lanes_per_round;
   const size_t f_cnt = one_per_lane ? np : n_lanes;
   HIPCHK(c, c->f_ws.reserve(f_cnt * 108 * 4));
-  if (one_per_lane) {
+  if (c->wide_fe && np <= c->wide_fe_max) {           // a handful of keys: one WAVE per pair
+    LAUNCH_WIDE(c, "miller_wide_1p", k_miller_wide_1p, np, (const int32_t*)h2, np, (const uint32_t*)kid2, (const int32_t*)c->prep_raw.p, (const uint8_t*)c->prep_ok.p, np,
+                (int32_t*)c->f_ws.p, np, (uint8_t*)c->flags.p, (const uint8_t*)st);
+  } else if (one_per_lane) {
     LAUNCH(c, "miller_hpk1p", k_miller_hpk1p, np, (const int32_t*)h2, np, (const uint32_t*)kid2, (const int32_t*)c->prep_raw.p, (const uint8_t*)c->prep_ok.p, np,
            (int32_t*)c->f_ws.p, np, (uint8_t*)c->flags.p, (const uint8_t*)st);
   } else {
@@ -1317,7 +1360,7 @@ int blsbn254_aggregate_verify(blsbn254_ctx* c, const uint8_t* pks, const uint8_t
   uint8_t ml[384]; int ok = 0, sig_ok = 0, v = 0;
   int rc;
   bool staged = false;
-  if (c->auto_prepare && n >= 1024) {                  // repeated keys: one pair per distinct key
+  if (c->auto_prepare && (n >= 1024 || (c->wide_fe && n + 1 <= c->wide_fe_max))) {   // repeated keys (or few pairs): one pair per distinct key
     bool took = false;
     rc = aggregate_verify_grouped(c, pks, msgs, off, n, agg_sig, dst, dst_len, valid, &took);
     if (rc || took) return rc;

@@ -1,0 +1,224 @@
+// wide.h -- ONE WAVE PER TUPLE arithmetic for the latency-bound tails of the path.
+//
+// The verification kernels run one lane per tuple: right for throughput, but a launch with few tuples (the ONE final
+// exponentiation of an aggregate verify, a single pairing, a small batch) is then the latency of one lane's serial chain --
+// 4.5 ms for the hard part of the final exponentiation (pairings.rs:117-178), whatever the batch size below 65 536.
+// Here the 64 lanes of a wave share one tuple: an Fp12 value lives in LDS as six Fp2 coefficients, an Fp12 product is 36
+// independent Fp2 products (one per lane) followed by six sums (w^6 = xi wraps the high half), a Granger-Scott cyclotomic
+// squaring (pairings.rs:68-115) is nine independent Fp2 squarings followed by six combinations.  Same field values as the
+// serial code (tower.h), hence the same bytes after the final canonicalisation; about 7 x shorter chains.
+//
+// Everything is written as PHASES: within a phase every lane works on its own operands and writes its own result; a
+// phase boundary is a workgroup barrier on the device (the workgroup is one wave) and the end of a loop over the 64 lane
+// ids in tests/hostsim, which runs this same code under the interval checker.
+#pragma once
+#include "pairing.h"
+
+namespace bn {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BN_WIDE_PHASE(lane, ...) { const uint32_t lane = threadIdx.x & 63u; { __VA_ARGS__ } __syncthreads(); }
+#define BN_WIDE_NOINLINE __attribute__((noinline))
+#else
+#define BN_WIDE_PHASE(lane, ...) { for (uint32_t lane = 0; lane < 64u; ++lane) { __VA_ARGS__ } }
+#define BN_WIDE_NOINLINE
+#endif
+
+// LDS region of one wave (dwords): the product area (36 Fp2) and WIDE_VALUES Fp12 values of 108 limbs, each stored as
+// its six tower slots c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2 (18 limbs per slot).
+enum : uint32_t { WIDE_PA_LIMBS = 36 * 18, WIDE_VALUES = 20, WIDE_LDS_DWORDS = WIDE_PA_LIMBS + 108 * WIDE_VALUES };
+// value ids of the hard part
+enum : uint32_t { WV_R = 0, WV_T = 1, WV_A = 2, WV_B = 3, WV_C = 4, WV_B2 = 5, WV_D2 = 6, WV_X = 7, WV_E = 8, WV_D = 9, WV_TMP = 10, WV_SLOT0 = 10 };   // chain slots 10..19 (TMP shares slot 0's place outside a chain)
+struct Wide { int32_t* lds; };
+
+BN_INL Ws wide_val(const Wide& w, uint32_t v, uint32_t slot) { return Ws{w.lds, 1, (WIDE_PA_LIMBS + 108u * v + 18u * slot) * 4u, false}; }
+BN_INL Ws wide_pa(const Wide& w, uint32_t idx) { return Ws{w.lds, 1, 18u * idx * 4u, false}; }
+// tower slot of the coefficient of w^k (f = sum_k f_k w^k, w^2 = v, w^6 = xi)
+BN_INL uint32_t wide_slot_of_w(uint32_t k) { return (k & 1u) ? 3u + (k >> 1) : (k >> 1); }
+// tower slot of z_i in the Granger-Scott labelling (z0 = c0.c0, z4 = c0.c1, z3 = c0.c2, z2 = c1.c0, z1 = c1.c1, z5 = c1.c2)
+BN_INL uint32_t wide_slot_of_z(uint32_t i) { return i == 0 ? 0u : i == 1 ? 4u : i == 2 ? 3u : i == 3 ? 2u : i == 4 ? 1u : 5u; }
+
+// x1 + ... + x6 per component, normalised (two passes)
+BN_INL Fp2 wide_sum6(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d, const Fp2& e, const Fp2& f) {
+  Fp2 s = {fp_lc4<1, 1, 1, 1>(a.c0, b.c0, c.c0, d.c0), fp_lc4<1, 1, 1, 1>(a.c1, b.c1, c.c1, d.c1)};
+  return {fp_lc3<1, 1, 1>(s.c0, e.c0, f.c0), fp_lc3<1, 1, 1>(s.c1, e.c1, f.c1)};
+}
+
+// dst = a * b.  Phase 1: lane (i, j) forms a_i b_j (coefficients of w^i, w^j).  Phase 2: lane k sums the products with
+// i + j = k and xi times those with i + j = k + 6.  dst may be a or b.
+BN_FUNC void wide_mul(const Wide& W, uint32_t dst, uint32_t a, uint32_t b) {
+  BN_WIDE_PHASE(lane,
+    if (lane < 36u) {
+      const uint32_t i = lane / 6u, j = lane - 6u * i;
+      const Fp2 x = fp2_load_mem(wide_val(W, a, wide_slot_of_w(i))), y = fp2_load_mem(wide_val(W, b, wide_slot_of_w(j)));
+      fp2_store_mem(wide_pa(W, lane), fp2_mul(x, y));
+    })
+  BN_WIDE_PHASE(lane,
+    if (lane < 6u) {
+      const uint32_t k = lane;
+      const Fp2 zero = fp2_zero();
+      Fp2 t[6];
+      BN_UNROLL for (uint32_t i = 0; i < 6u; ++i) t[i] = fp2_load_mem(wide_pa(W, 6u * i + (k + 6u - i) % 6u));
+      const Fp2 sd = wide_sum6(t[0], fp2_select(1u <= k, t[1], zero), fp2_select(2u <= k, t[2], zero), fp2_select(3u <= k, t[3], zero),
+                               fp2_select(4u <= k, t[4], zero), fp2_select(5u <= k, t[5], zero));
+      const Fp2 sw = wide_sum6(zero, fp2_select(1u > k, t[1], zero), fp2_select(2u > k, t[2], zero), fp2_select(3u > k, t[3], zero),
+                               fp2_select(4u > k, t[4], zero), fp2_select(5u > k, t[5], zero));
+      fp2_store_mem(wide_val(W, dst, wide_slot_of_w(k)), fp2_add_mul_xi(sd, sw));
+    })
+}
+// v = v^2 for v in the cyclotomic subgroup (same values as fp12_cyclotomic_sqr, tower.h).  Phase 1: lane (pair p, kind q)
+// squares a, b or a + b of the pair (z0, z1), (z2, z3), (z4, z5).  Phase 2: lane o forms r_o in the slot of z_o.
+BN_FUNC void wide_cyc_sqr(const Wide& W, uint32_t v) {
+  BN_WIDE_PHASE(lane,
+    if (lane < 9u) {
+      const uint32_t p = lane / 3u, q = lane - 3u * p;
+      const Fp2 a = fp2_load_mem(wide_val(W, v, wide_slot_of_z(2u * p))), b = fp2_load_mem(wide_val(W, v, wide_slot_of_z(2u * p + 1u)));
+      const Fp2 s = fp2_norm(fp2_add(a, b));
+      fp2_store_mem(wide_pa(W, lane), fp2_sqr(fp2_select(q == 0u, a, fp2_select(q == 1u, b, s))));
+    })
+  BN_WIDE_PHASE(lane,
+    if (lane < 6u) {
+      const uint32_t o = lane;
+      const uint32_t p = (o < 2u) ? 0u : (o < 4u) ? 2u : 1u;       // r0, r1 <- (z0, z1); r2, r3 <- (z4, z5); r4, r5 <- (z2, z3)
+      const Fp4Sq q = {fp2_load_mem(wide_pa(W, 3u * p)), fp2_load_mem(wide_pa(W, 3u * p + 1u)), fp2_load_mem(wide_pa(W, 3u * p + 2u))};
+      const Ws zw = wide_val(W, v, wide_slot_of_z(o));
+      const Fp2 z = fp2_load_mem(zw);
+      Fp2 r;
+      if (o == 2u) {                                              // z2 = 3 xi t5 + 2 z2, t5 = s - ta - tb brought back below ~p first
+        const Fp2 t5 = {fp_lc4<1, -1, -1, 0, true>(q.s.c0, q.ta.c0, q.tb.c0, q.s.c0), fp_lc4<1, -1, -1, 0, true>(q.s.c1, q.ta.c1, q.tb.c1, q.s.c1)};
+        r = {fp_lc3<27, -3, 2>(t5.c0, t5.c1, z.c0), fp_lc3<3, 27, 2>(t5.c0, t5.c1, z.c1)};
+      } else if (o == 1u || o == 5u) {
+        r = cyc_c1(q, z);
+      } else {
+        r = cyc_c0(q, z);
+      }
+      fp2_store_mem(zw, fp2_norm(r));
+    })
+}
+// dst = conj(src) = (c0, -c1); dst = src (plain copy) when neg is false
+BN_FUNC void wide_conj_or_copy(const Wide& W, uint32_t dst, uint32_t src, bool neg) {
+  BN_WIDE_PHASE(lane,
+    if (lane < 6u) {
+      const Fp2 x = fp2_load_mem(wide_val(W, src, lane));
+      fp2_store_mem(wide_val(W, dst, lane), fp2_select(neg && lane >= 3u, fp2_norm(fp2_neg(x)), x));
+    })
+}
+// dst = Frobenius^K(src): the coefficient of w^k becomes conj^K(.) * xi^(k (p^K - 1) / 6)
+template <int K>
+BN_FUNC void wide_frob(const Wide& W, uint32_t dst, uint32_t src) {
+  BN_WIDE_PHASE(lane,
+    if (lane < 6u) {
+      const uint32_t k = lane, g = k ? k - 1u : 0u;
+      Fp2 c = fp2_load_mem(wide_val(W, src, wide_slot_of_w(k)));
+      if (K & 1) c = fp2_norm(fp2_conj(c));
+      Fp2 m;
+      if (K == 1) m = fp2_mul(c, fp2_from_limbs(bnc::GAMMA1[g]));
+      else if (K == 2) m = fp2_mul_fp(c, fp_from_limbs(bnc::GAMMA2[g]));
+      else m = fp2_mul(c, fp2_from_limbs(bnc::GAMMA3[g]));
+      fp2_store_mem(wide_val(W, dst, wide_slot_of_w(k)), fp2_select(k != 0u, m, c));
+    })
+}
+
+// ---- Miller loops over prepared keys (no point arithmetic): per loop digit  R <- R^2, then R <- R * L  with the line value L
+// assembled by five lanes from the key's table and the tuple's coordinates.  L is stored as a full Fp12 value (zero slots
+// where the line has no coefficient) and multiplied in by the general wide_mul: at one wave per tuple the chain length counts,
+// not the 6 of 36 products that are spent on zeros.
+// One pair, raw line triple (54 limbs at `line`), affine point (px, py) at pt (LDS, 18 limbs): L = c0 py + c1 px w + c2 w^3 (ell, pairing.h)
+BN_FUNC void wide_line_eval_1(const Wide& W, uint32_t dst, const Ws& line, const Ws& pt) {
+  BN_WIDE_PHASE(lane,
+    if (lane < 6u) {
+      const uint32_t s = lane;
+      const bool used = s == 0u || s == 3u || s == 4u;              // tower slots of w^0, w^1, w^3
+      const Fp2 coef = fp2_load_limbs(ws_at(line, s == 3u ? 18u : s == 4u ? 36u : 0u));
+      const Fp px = fp_load_mem(pt), py = fp_load_mem(ws_at(pt, 9));
+      const Fp sc = fp_select(s == 0u, py, fp_select(s == 3u, px, fp_one()));
+      fp2_store_mem(wide_val(W, dst, s), fp2_select(used, fp2_mul_fp(coef, sc), fp2_zero()));
+    })
+}
+// Two pairs with the pair table of ell_pair_expanded (pairing.h): e = this step's nine products T0..T8 (162 limbs), cw = the nine
+// coordinate values X, Y, Z, xs X, ys Y, xs Z, ys Z, ys X, xs Y (LDS, 81 limbs):
+//   L = (T0 ysY + T1 Z) + T2 xsX v + (T3 xsZ + T4 X) v^2 + [(T5 ysX + T6 xsY) + (T7 ysZ + T8 Y) v] w
+BN_FUNC void wide_line_eval_pair(const Wide& W, uint32_t dst, const Ws& e, const Ws& cw) {
+  BN_WIDE_PHASE(lane,
+    if (lane < 6u) {
+      const uint32_t s = lane;                                      // tower slot; slot 5 (v^2 w) has no coefficient
+      const uint32_t ta = s == 0u ? 0u : s == 1u ? 2u : s == 2u ? 3u : s == 3u ? 5u : 7u, tb = s == 0u ? 1u : s == 1u ? 2u : s == 2u ? 4u : s == 3u ? 6u : 8u;
+      const uint32_t ca = s == 0u ? 4u : s == 1u ? 3u : s == 2u ? 5u : s == 3u ? 7u : 6u, cb = s == 0u ? 2u : s == 2u ? 0u : s == 3u ? 8u : 1u;
+      const Fp sa = fp_load_mem(ws_at(cw, 9u * ca));
+      const Fp sb = fp_select(s == 1u, fp_zero(), fp_load_mem(ws_at(cw, 9u * cb)));      // T2 xsX stands alone
+      const Fp2 v = fp2_dot_fp(fp2_load_limbs(ws_at(e, 18u * ta)), sa, fp2_load_limbs(ws_at(e, 18u * tb)), sb);
+      fp2_store_mem(wide_val(W, dst, s), fp2_select(s < 5u, v, fp2_zero()));
+    })
+}
+enum : uint32_t { WOP_MUL = 0, WOP_SQR = 1, WOP_CONJ = 2, WOP_COPY = 3, WOP_FROB1 = 4, WOP_FROB2 = 5, WOP_FROB3 = 6 };
+// one primitive; WOP_SQR squares `dst` in place `a` times.  A real function: every primitive is instantiated once.
+BN_HD BN_WIDE_NOINLINE inline void wide_exec(const Wide& W, uint32_t op, uint32_t dst, uint32_t a, uint32_t b) {
+  switch (op) {
+    case WOP_MUL: wide_mul(W, dst, a, b); break;
+    case WOP_SQR: for (uint32_t q = 0; q < a; ++q) wide_cyc_sqr(W, dst); break;
+    case WOP_CONJ: wide_conj_or_copy(W, dst, a, true); break;
+    case WOP_COPY: wide_conj_or_copy(W, dst, a, false); break;
+    case WOP_FROB1: wide_frob<1>(W, dst, a); break;
+    case WOP_FROB2: wide_frob<2>(W, dst, a); break;
+    default: wide_frob<3>(W, dst, a); break;
+  }
+}
+enum : uint32_t { WV_L = 1 };                                       // the line value (the Miller loops do not use WV_T)
+// the loop of miller_loop_1prepared / miller_loop_prepared (pairing.h); pair = false: raw table of 54-limb lines and pt = (px, py);
+// pair = true: pair table of 162-limb entries and pt = the nine coordinate values.  Result in WV_R.
+BN_HD inline void wide_miller_prepared(const Wide& W, const Ws& table, const Ws& pt, bool pair) {
+  BN_WIDE_PHASE(lane,
+    if (lane < 6u) fp2_store_mem(wide_val(W, WV_R, lane), lane == 0u ? fp2_one() : fp2_zero());
+  )
+  const size_t per = pair ? 162 : 54;
+  int ti = 0;
+  for (int j = bnc::ATE_NAF_LEN - 2; j >= -2; --j) {                // j = -1, -2: the two final lines (no squaring)
+    if (j >= 0) wide_exec(W, WOP_MUL, WV_R, WV_R, WV_R);
+    const int lines = j >= 0 ? (ate_naf_digit(j) != 0 ? 2 : 1) : 1;
+    for (int q = 0; q < lines; ++q) {
+      const Ws ln = ws_at(table, per * (size_t)ti++);
+      if (pair) wide_line_eval_pair(W, WV_L, ln, pt); else wide_line_eval_1(W, WV_L, ln, pt);
+      wide_exec(W, WOP_MUL, WV_R, WV_R, WV_L);
+    }
+  }
+}
+
+// out = in^x by the addition chain of cyclotomic_exp_x_chain (pairing.h): 62 squarings + 17 products; R is the accumulator
+BN_HD inline void wide_exp_x(const Wide& W, uint32_t out, uint32_t in) {
+  const ExpxOp prog[22] = {{-1, 1, -1, 1}, {-1, 1, -1, 2}, {-1, 1, -1, 3}, {-1, 1, 0, 4}, {-1, 0, 1, 5}, {-1, 0, 0, 6}, {3, 0, 4, 7},
+                           {5, 0, 6, 8}, {-1, 0, 1, 9}, {4, 1, -1, -1}, {-1, 6, 2, -1}, {-1, 0, 7, -1}, {-1, 7, 7, -1}, {-1, 8, 9, -1},
+                           {-1, 0, 1, -1}, {-1, 6, 4, -1}, {-1, 8, 9, -1}, {-1, 6, 9, -1}, {-1, 10, -1, -1}, {-1, 0, 8, -1}, {-1, 6, 9, -1},
+                           {-1, 0, 3, -1}};
+  wide_exec(W, WOP_COPY, WV_SLOT0, in, 0);
+  wide_exec(W, WOP_COPY, WV_R, in, 0);
+  for (int k = 0; k < 22; ++k) {
+    const ExpxOp op = prog[k];
+    if (op.load >= 0) wide_exec(W, WOP_COPY, WV_R, WV_SLOT0 + (uint32_t)op.load, 0);
+    if (op.sq > 0) wide_exec(W, WOP_SQR, WV_R, (uint32_t)op.sq, 0);
+    if (op.mul >= 0) wide_exec(W, WOP_MUL, WV_R, WV_R, WV_SLOT0 + (uint32_t)op.mul);
+    if (op.store >= 0) wide_exec(W, WOP_COPY, WV_SLOT0 + (uint32_t)op.store, WV_R, 0);
+  }
+  wide_exec(W, WOP_COPY, out, WV_R, 0);
+}
+// The hard part of the final exponentiation (fe_h1 / fe_h2 / fe_h3 of pairing.h around three t -> t^x): WV_T holds
+// t = f^((p^6-1)(p^2+1)); the result is left in WV_R.
+BN_HD inline void wide_fe_hard(const Wide& W) {
+  wide_exp_x(W, WV_X, WV_T);                                   // x0 = t^x
+  wide_exec(W, WOP_CONJ, WV_A, WV_X, 0); wide_exec(W, WOP_SQR, WV_A, 1, 0);          // a = t^-2x
+  wide_exec(W, WOP_COPY, WV_B, WV_A, 0); wide_exec(W, WOP_SQR, WV_B, 1, 0);          // t^-4x
+  wide_exec(W, WOP_MUL, WV_B, WV_A, WV_B);                                           // b = t^-6x
+  wide_exp_x(W, WV_X, WV_B);                                   // x1 = b^x = t^(-6x^2)
+  wide_exec(W, WOP_CONJ, WV_C, WV_X, 0);                                             // c = t^(6x^2)
+  wide_exec(W, WOP_CONJ, WV_B2, WV_B, 0); wide_exec(W, WOP_MUL, WV_B2, WV_C, WV_B2); // b2 = c conj(b)
+  wide_exec(W, WOP_COPY, WV_D2, WV_C, 0); wide_exec(W, WOP_SQR, WV_D2, 1, 0);        // d2 = c^2
+  wide_exp_x(W, WV_X, WV_D2);                                  // x2 = d2^x = t^(12x^3)
+  wide_exec(W, WOP_MUL, WV_E, WV_B2, WV_X);                                          // e
+  wide_exec(W, WOP_MUL, WV_D, WV_A, WV_E);                                           // d
+  wide_exec(W, WOP_MUL, WV_R, WV_C, WV_E); wide_exec(W, WOP_MUL, WV_R, WV_T, WV_R);  // l0 = t (c e)
+  wide_exec(W, WOP_FROB1, WV_TMP, WV_D, 0); wide_exec(W, WOP_MUL, WV_R, WV_R, WV_TMP);
+  wide_exec(W, WOP_FROB2, WV_TMP, WV_E, 0); wide_exec(W, WOP_MUL, WV_R, WV_R, WV_TMP);
+  wide_exec(W, WOP_CONJ, WV_TMP, WV_T, 0); wide_exec(W, WOP_MUL, WV_TMP, WV_TMP, WV_D);   // l3 = conj(t) d
+  wide_exec(W, WOP_FROB3, WV_TMP, WV_TMP, 0); wide_exec(W, WOP_MUL, WV_R, WV_R, WV_TMP);
+}
+
+}  // namespace bn

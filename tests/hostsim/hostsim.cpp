@@ -8,6 +8,8 @@
 #include "../../bls-bn254_amd/csrc/lane_ops.h"
 #include "../../bls-bn254_amd/csrc/keygen.h"
 #include "../../bls-bn254_amd/csrc/glv.h"
+#include "../../bls-bn254_amd/csrc/wide.h"
+#include <vector>
 #include <cstring>
 
 using namespace bn;
@@ -99,6 +101,80 @@ int hs_final_exp(const uint8_t* in, uint8_t* out) {
   Fp12 f = fp12_from_be(in, ok);
   if (!ok) return 4;
   fp12_to_be(out, final_exponentiation(f));
+  return 0;
+}
+// wide.h (one wave per tuple) under the interval checker: the 64 lanes of a phase run one after the other over a host
+// array standing in for the wave's LDS region.  Final exponentiation = serial easy part + wide hard part.
+static void wide_put(const Wide& W, uint32_t v, const Fp12& f) {
+  const Fp6* h[2] = {&f.c0, &f.c1};
+  for (int j = 0; j < 2; ++j) {
+    fp2_store_mem(wide_val(W, v, 3 * j + 0), fp2_norm(h[j]->c0)); fp2_store_mem(wide_val(W, v, 3 * j + 1), fp2_norm(h[j]->c1));
+    fp2_store_mem(wide_val(W, v, 3 * j + 2), fp2_norm(h[j]->c2));
+  }
+}
+static Fp12 wide_get(const Wide& W, uint32_t v) {
+  return {{fp2_load_mem(wide_val(W, v, 0)), fp2_load_mem(wide_val(W, v, 1)), fp2_load_mem(wide_val(W, v, 2))},
+          {fp2_load_mem(wide_val(W, v, 3)), fp2_load_mem(wide_val(W, v, 4)), fp2_load_mem(wide_val(W, v, 5))}};
+}
+int hs_final_exp_wide(const uint8_t* in, uint8_t* out) {
+  bool ok;
+  Fp12 f = fp12_from_be(in, ok);
+  if (!ok) return 4;
+  std::vector<int32_t> lds(WIDE_LDS_DWORDS, 0);
+  Wide W{lds.data()};
+  wide_put(W, WV_T, fe_easy(f));
+  wide_fe_hard(W);
+  fp12_to_be(out, wide_get(W, WV_R));
+  return 0;
+}
+// single primitives against their serial counterparts: op 0 a*b, 1 cyclotomic square of a (a must be cyclotomic), 2 conj, 4..6 Frobenius^1..3
+int hs_wide_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out_wide, uint8_t* out_serial) {
+  bool ok1, ok2 = true;
+  Fp12 x = fp12_from_be(a, ok1), y = b ? fp12_from_be(b, ok2) : fp12_one();
+  if (!ok1 || !ok2) return 4;
+  std::vector<int32_t> lds(WIDE_LDS_DWORDS, 0);
+  Wide W{lds.data()};
+  wide_put(W, WV_A, x); wide_put(W, WV_B, y);
+  Fp12 r;
+  switch (op) {
+    case 0: wide_exec(W, WOP_MUL, WV_R, WV_A, WV_B); r = fp12_mul(x, y); break;
+    case 1: wide_exec(W, WOP_COPY, WV_R, WV_A, 0); wide_exec(W, WOP_SQR, WV_R, 1, 0); r = fp12_cyclotomic_sqr(x); break;
+    case 2: wide_exec(W, WOP_CONJ, WV_R, WV_A, 0); r = fp12_conj(x); break;
+    case 4: wide_exec(W, WOP_FROB1, WV_R, WV_A, 0); r = fp12_frob<1>(x); break;
+    case 5: wide_exec(W, WOP_FROB2, WV_R, WV_A, 0); r = fp12_frob<2>(x); break;
+    case 6: wide_exec(W, WOP_FROB3, WV_R, WV_A, 0); r = fp12_frob<3>(x); break;
+    default: return -1;
+  }
+  fp12_to_be(out_wide, wide_get(W, WV_R));
+  fp12_to_be(out_serial, r);
+  return 0;
+}
+// wide Miller loops over prepared keys against the serial loops of pairing.h: one pair from the raw line table (out[0] wide,
+// out[1] serial) and the verify pair (sig, -G2gen) x (H, pk) from the pair table (out[2] wide, out[3] serial); 4 x 384 bytes
+int hs_miller_wide(const uint8_t* sig, const uint8_t* h, const uint8_t* pk, uint8_t* out) {
+  bool o1, o2, o3;
+  G1A s = g1_decode(sig, o1), hp = g1_decode(h, o2);
+  G2A q = g2_decode(pk, o3);
+  if (!o1 || !o2 || !o3) return 1;
+  std::vector<int32_t> raw(BN_NEG_G2_LINES * 54), exp_(BN_NEG_G2_LINES * 162), lds(WIDE_LDS_DWORDS, 0), col(256, 0);
+  const Ws rw = {raw.data(), 1, 0, false}, ew = {exp_.data(), 1, 0, false};
+  g2_prepare_lines(q, rw);
+  for (int t = 0; t < BN_NEG_G2_LINES; ++t)
+    line_pair_expand(line_from_table(BN_NEG_G2_LINE_TABLE[t]), line_load_limbs(ws_at(rw, 54 * (size_t)t)), ws_at(ew, 162 * (size_t)t));
+  Wide W{lds.data()};
+  const Ws pt = {col.data(), 1, 0, false};
+  fp_store_mem(pt, fp_norm(hp.x)); fp_store_mem(ws_at(pt, 9), fp_norm(hp.y));
+  wide_miller_prepared(W, rw, pt, false);
+  fp12_to_be(out, wide_get(W, WV_R));
+  fp12_to_be(out + 384, miller_loop_1prepared(pt, rw));
+  const Fp xs = fp_norm(s.x), ys = fp_norm(s.y), X = fp_norm(hp.x), Y = fp_norm(hp.y), Z = fp_one();
+  const Ws cw = {col.data() + 32, 1, 0, false};
+  fp_store_mem(cw, X); fp_store_mem(ws_at(cw, 9), Y); fp_store_mem(ws_at(cw, 18), Z);
+  fp_store_mem(ws_at(cw, 27), fp_mul(xs, X)); fp_store_mem(ws_at(cw, 36), fp_mul(ys, Y)); fp_store_mem(ws_at(cw, 45), fp_mul(xs, Z));
+  fp_store_mem(ws_at(cw, 54), fp_mul(ys, Z)); fp_store_mem(ws_at(cw, 63), fp_mul(ys, X)); fp_store_mem(ws_at(cw, 72), fp_mul(xs, Y));
+  wide_miller_prepared(W, ew, cw, true);
+  fp12_to_be(out + 768, wide_get(W, WV_R));
+  fp12_to_be(out + 1152, miller_loop_prepared(cw, ew));
   return 0;
 }
 void hs_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* out) {

@@ -590,6 +590,40 @@ def test_verify_batch_rlc_edge_cases(eng, oracle, pyref, M, monkeypatch):
         e.close()
 
 
+def test_wide_final_exponentiation_equals_serial(eng, oracle, pyref, M, monkeypatch):
+    """Launches of at most 4096 tuples run the hard part of the final exponentiation with one WAVE per tuple
+    (k_fe_wide.hip); larger ones, or BLSBN254_WIDE_FE=0, with one lane per tuple: same Gt bytes, same bitmaps, at the
+    switch-over sizes and through every mode of the finishing step (Gt bytes, verify bitmap, single flag)."""
+    rnd = random.Random(4096)
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    base = 24
+    p1 = [oracle.g1_mul(G1, rnd.randrange(1, pyref.R)) for _ in range(base)]
+    p2 = [oracle.g2_mul(G2, rnd.randrange(1, pyref.R)) for _ in range(base)]
+    want = oracle.pairing_batch(b"".join(p1), b"".join(p2), base)
+    monkeypatch.setenv("BLSBN254_WIDE_FE", "0")
+    serial = M.Engine(0)
+    monkeypatch.delenv("BLSBN254_WIDE_FE")
+    try:
+        for n in (1, 63, 4096, 4097):
+            g1 = b"".join(p1[i % base] for i in range(n)); g2 = b"".join(p2[i % base] for i in range(n))
+            exp = b"".join(want[384 * (i % base):384 * (i % base) + 384] for i in range(n))
+            assert eng.pairing_batch(g1, g2, n) == exp                   # wide up to 4096, serial beyond
+            if n <= 63:
+                assert serial.pairing_batch(g1, g2, n) == exp            # serial kernels on the small sizes too
+        dst = M.DEFAULT_DST
+        for n in (5, 300):
+            pks, msgs, sigs, e = synth.make_batch(oracle, n, dst, invalid_every=4, uniq=20)
+            assert eng.verify_batch(pks, msgs, sigs, dst) == serial.verify_batch(pks, msgs, sigs, dst) == synth.bitmap_of(e)
+        sks = [synth.sk_of(k) for k in range(5)]
+        pk5 = b"".join(oracle.sk_to_pk(s) for s in sks); m5 = [synth.msg_of(i) for i in range(5)]
+        agg = oracle.aggregate_sigs(b"".join(oracle.sign(s, m, dst) for s, m in zip(sks, m5)), 5)
+        for e_ in (eng, serial):
+            assert e_.aggregate_verify(pk5, m5, agg, dst) is True
+            assert e_.aggregate_verify(pk5, m5[:4] + [b"x"], agg, dst) is False
+    finally:
+        serial.close()
+
+
 def test_chunked_entry_points(oracle, pyref, M, monkeypatch):
     """Batches larger than the per-launch chunk (4 Mi tuples in production; forced to 64 here through the
     BLSBN254_CHUNK_LANES test knob) are processed chunk by chunk: same results as the one-launch path."""
@@ -628,7 +662,7 @@ def test_chunked_prepared_paths(oracle, M, monkeypatch):
     try:
         p0, e0 = e.path_stats()
         assert e.verify_batch(pks, msgs, sigs, dst) == want
-        assert e.path_stats() == (p0 + 2, e0 + 1)                  # two full chunks on the prepared path, the 900-tuple tail (< 1024) on the exact one
+        assert e.path_stats() == (p0 + 3, e0)                      # every chunk on the prepared path (the 900-tuple tail as a small chunk: one wave per tuple)
         keys = sorted(set(pks[128 * i:128 * i + 128] for i in range(n)))
         index = {k: j for j, k in enumerate(keys)}
         prep = e.g2_prepare_batch(b"".join(keys), len(keys))
@@ -793,11 +827,12 @@ def test_prepared_key_path_equals_exact_path(eng, oracle, M, n, pool):
     assert oracle.verify_batch(pks, msgs, sigs, dst, nthreads=16) == want       # ~3 s of CPU at n = 20000
 
 
-@pytest.mark.parametrize("pool,prepared", [(512, True), (513, False)])
+@pytest.mark.parametrize("pool,prepared", [(2560, True), (2561, False)])
 def test_prepared_path_threshold(eng, oracle, M, pool, prepared):
-    """the switch-over: a chunk takes the prepared path exactly when at most half of its public keys are distinct"""
+    """the switch-over: a chunk of more than 4096 tuples takes the prepared path exactly when at most half of its public keys
+    are distinct (smaller chunks always do: their Miller loops and final exponentiations run one wave per tuple off the tables)"""
     dst = M.DEFAULT_DST
-    n = 1024
+    n = 5120
     skb = b"".join(synth.sk_of(k).to_bytes(32, "big") for k in range(pool))
     pkp = eng.sk_to_pk_batch(skb, pool)
     msgs = [synth.msg_of(90000 + i) for i in range(n)]
@@ -814,7 +849,7 @@ def test_prepared_path_threshold(eng, oracle, M, pool, prepared):
 def test_prepared_path_not_taken_for_distinct_keys(eng, oracle, M):
     """mostly distinct keys: the de-duplication finds more than n / 2 of them and the exact path runs"""
     dst = M.DEFAULT_DST
-    n = 1100
+    n = 4200
     sks = [synth.sk_of(k) for k in range(n)]
     pks = eng.sk_to_pk_batch(b"".join(s.to_bytes(32, "big") for s in sks), n)
     msgs = [synth.msg_of(i) for i in range(n)]

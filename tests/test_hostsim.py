@@ -214,3 +214,43 @@ def test_parked_and_prepared_miller_loops(hs, oracle, pyref):
         assert o1.raw == want and o2.raw == oracle.final_exponentiation(want, 1)
         hs.hs_miller_prepared(sig, ha, qa, 5, o1, o2)            # H = (5x : 5y : 5): differs by 5^88 in Fp, gone after the final exponentiation
         assert o1.raw != want and o2.raw == oracle.final_exponentiation(want, 1)
+
+
+def test_wide_final_exponentiation_one_wave_per_tuple(hs, oracle, pyref):
+    """wide.h: the hard part of the final exponentiation with the 64 lanes of a wave sharing ONE tuple (Fp12 product = 36
+    Fp2 products + 6 sums, cyclotomic squaring = 9 Fp2 squarings + 6 combinations), run here phase by phase over the 64 lane
+    ids under the interval checker: every primitive equals its serial counterpart of tower.h byte for byte, and
+    fe_easy + wide hard part == final_exponentiation == the oracle."""
+    rnd = random.Random(77)
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+
+    def ml():
+        return oracle.miller_loop_batch(oracle.g1_mul(G1, rnd.randrange(1, pyref.R)), oracle.g2_mul(G2, rnd.randrange(1, pyref.R)), 1)
+    a = ctypes.create_string_buffer(384); b = ctypes.create_string_buffer(384)
+    x, y = ml(), ml()
+    for op in (0, 2, 4, 5, 6):                                   # product, conjugate, Frobenius^1..3 on arbitrary Fp12 values
+        assert hs.hs_wide_op(op, x, y, a, b) == 0 and a.raw == b.raw, op
+    one = (1).to_bytes(32, "big") + bytes(352)
+    assert hs.hs_wide_op(0, x, one, a, b) == 0 and a.raw == b.raw == x
+    gt = oracle.pairing_batch(oracle.g1_mul(G1, 5), oracle.g2_mul(G2, 7), 1)
+    assert hs.hs_wide_op(1, gt, None, a, b) == 0 and a.raw == b.raw                                 # cyclotomic squaring
+    assert a.raw == oracle.gt_mul(gt, gt) if hasattr(oracle, "gt_mul") else True
+    for m in (x, y, ml()):
+        assert hs.hs_final_exp_wide(m, a) == 0 and hs.hs_final_exp(m, b) == 0
+        assert a.raw == b.raw == oracle.final_exponentiation(m, 1)
+
+
+def test_wide_miller_loops_over_prepared_keys(hs, oracle, pyref):
+    """wide.h Miller loops (R <- R^2, R <- R * L with L assembled by five lanes from the key's table): the one-pair loop equals
+    miller_loop_1prepared and the oracle's Miller value, the verify loop over the pair table equals miller_loop_prepared, byte
+    for byte, under the interval checker."""
+    rnd = random.Random(78)
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    out = ctypes.create_string_buffer(4 * 384)
+    for _ in range(2):
+        sig, h = (oracle.g1_mul(G1, rnd.randrange(1, pyref.R)) for _ in range(2))
+        pk = oracle.g2_mul(G2, rnd.randrange(1, pyref.R))
+        assert hs.hs_miller_wide(sig, h, pk, out) == 0
+        w1, s1, w2, s2 = (out.raw[384 * k:384 * k + 384] for k in range(4))
+        assert w1 == s1 == oracle.miller_loop_batch(h, pk, 1)
+        assert w2 == s2
