@@ -343,7 +343,11 @@ static int miller_to_ws(blsbn254_ctx* c, const uint8_t* d_g1, const uint8_t* d_g
   CHECK_LANES(c, n);
   HIPCHK(c, c->f_ws.reserve(n * 108 * 4));
   HIPCHK(c, c->status.reserve(n));
-  LAUNCH(c, "miller_1", k_miller_1, n, d_g1, d_g2, n, (int32_t*)c->f_ws.p, n, (uint8_t*)c->status.p);
+  if (c->wide_fe && n <= c->wide_fe_max / 2) {        // few pairs: one wave per pair (lane 0 runs the G2 point arithmetic); the serial part makes the chain ~2 x a prepared one
+    LAUNCH_WIDE(c, "miller_wide_1", k_miller_wide_1, n, d_g1, d_g2, n, (int32_t*)c->f_ws.p, n, (uint8_t*)c->status.p);
+  } else {
+    LAUNCH(c, "miller_1", k_miller_1, n, d_g1, d_g2, n, (int32_t*)c->f_ws.p, n, (uint8_t*)c->status.p);
+  }
   return 0;
 }
 static int decode_status_rc(blsbn254_ctx* c, const uint8_t* d_status, size_t n) {

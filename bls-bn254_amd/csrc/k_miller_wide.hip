@@ -64,3 +64,27 @@ __global__ void __launch_bounds__(64) k_miller_wide_1p(const int32_t* h_ws, size
   wide_miller_prepared(W, Ws{const_cast<int32_t*>(table), 1, key * (uint32_t)(BN_NEG_G2_LINES * 54 * 4), true}, pt, false);
   wide_store_result(W, f_ws, f_stride, i, live);
 }
+
+// k_miller_1 (pairing / miller_loop of arbitrary (G1, G2) pairs) with one wave per pair: lane 0 runs the point arithmetic of the
+// variable G2 point, the wave the Fp12 arithmetic.  status as lane_miller_1: bit 0 g1 decodes, bit 1 g2 decodes, bit 2 identity.
+__global__ void __launch_bounds__(64) k_miller_wide_1(const uint8_t* g1, const uint8_t* g2, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status) {
+  __shared__ int32_t lds[WIDE_PA_LIMBS + 108 * 2 + 18 + 54];       // product area, R, L, (px, py), the parked line triple
+  const size_t i = blockIdx.x;
+  if (i >= n) return;
+  const Wide W{lds};
+  bool ok1, ok2;
+  G1A p = g1_decode(g1 + 64 * i, ok1);
+  G2A q = g2_decode(g2 + 128 * i, ok2);
+  const bool ident = p.inf | q.inf, bad = ident | !ok1 | !ok2;      // identity or undecodable operands: generators, result replaced by 1
+  G1A gp; gp.x = fp_one(); gp.y = fp_norm(fp_add(fp_one(), fp_one()));
+  p.x = fp_select(bad, gp.x, p.x); p.y = fp_select(bad, gp.y, p.y);
+  q.x = fp2_norm(fp2_select(bad, fp2_const(bnc::G2_GEN_X), q.x)); q.y = fp2_norm(fp2_select(bad, fp2_const(bnc::G2_GEN_Y), q.y)); q.inf = false;
+  const Ws pt = {lds, 1, (WIDE_PA_LIMBS + 108u * 2u) * 4u, false}, lnw = {lds, 1, (WIDE_PA_LIMBS + 108u * 2u + 18u) * 4u, false};
+  if (threadIdx.x == 0) {
+    fp_store_mem(pt, fp_norm(p.x)); fp_store_mem(ws_at(pt, 9), fp_norm(p.y));
+    status[i] = (uint8_t)((ok1 ? 1 : 0) | (ok2 ? 2 : 0) | (ident ? 4 : 0));
+  }
+  __syncthreads();
+  wide_miller_1(W, q, pt, lnw);
+  wide_store_result(W, f_ws, f_stride, i, !bad);
+}

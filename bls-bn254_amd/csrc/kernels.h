@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(64) k_miller_wide_prepared(const uint32_t* per
                                                              const int32_t* table, const uint8_t* key_ok, size_t n, int32_t* f_ws, uint8_t* flags);
 __global__ void __launch_bounds__(64) k_miller_wide_1p(const int32_t* h_ws, size_t h_stride, const uint32_t* kid, const int32_t* table, const uint8_t* key_ok, size_t n,
                                                        int32_t* f_ws, size_t f_stride, uint8_t* flags, const uint8_t* skip);
+__global__ void __launch_bounds__(64) k_miller_wide_1(const uint8_t* g1, const uint8_t* g2, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status);
 __global__ void __launch_bounds__(64) k_fe_hard_wide(const int32_t* t_ws, size_t n, size_t stride, const uint8_t* flags, const uint8_t* sub_ok,
                                                      uint8_t* one, uint8_t* gt_bytes, int* is_one, int mode);
 BN_KERNEL k_fp12_from_bytes(const uint8_t* in, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status);

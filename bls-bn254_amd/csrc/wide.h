@@ -124,12 +124,15 @@ BN_FUNC void wide_frob(const Wide& W, uint32_t dst, uint32_t src) {
 // where the line has no coefficient) and multiplied in by the general wide_mul: at one wave per tuple the chain length counts,
 // not the 6 of 36 products that are spent on zeros.
 // One pair, raw line triple (54 limbs at `line`), affine point (px, py) at pt (LDS, 18 limbs): L = c0 py + c1 px w + c2 w^3 (ell, pairing.h)
+// (PARKED: the triple was written by fp2_store_mem -- a line just computed by lane 0 -- instead of read from a key's table)
+template <bool PARKED = false>
 BN_FUNC void wide_line_eval_1(const Wide& W, uint32_t dst, const Ws& line, const Ws& pt) {
   BN_WIDE_PHASE(lane,
     if (lane < 6u) {
       const uint32_t s = lane;
       const bool used = s == 0u || s == 3u || s == 4u;              // tower slots of w^0, w^1, w^3
-      const Fp2 coef = fp2_load_limbs(ws_at(line, s == 3u ? 18u : s == 4u ? 36u : 0u));
+      const Ws lw = ws_at(line, s == 3u ? 18u : s == 4u ? 36u : 0u);
+      const Fp2 coef = PARKED ? fp2_load_mem(lw) : fp2_load_limbs(lw);
       const Fp px = fp_load_mem(pt), py = fp_load_mem(ws_at(pt, 9));
       const Fp sc = fp_select(s == 0u, py, fp_select(s == 3u, px, fp_one()));
       fp2_store_mem(wide_val(W, dst, s), fp2_select(used, fp2_mul_fp(coef, sc), fp2_zero()));
@@ -177,12 +180,42 @@ BN_HD inline void wide_miller_prepared(const Wide& W, const Ws& table, const Ws&
     const int lines = j >= 0 ? (ate_naf_digit(j) != 0 ? 2 : 1) : 1;
     for (int q = 0; q < lines; ++q) {
       const Ws ln = ws_at(table, per * (size_t)ti++);
-      if (pair) wide_line_eval_pair(W, WV_L, ln, pt); else wide_line_eval_1(W, WV_L, ln, pt);
+      if (pair) wide_line_eval_pair(W, WV_L, ln, pt); else wide_line_eval_1<false>(W, WV_L, ln, pt);
       wide_exec(W, WOP_MUL, WV_R, WV_R, WV_L);
     }
   }
 }
 
+// The one-pair loop with a VARIABLE G2 point (miller_loop_1, pairing.h; pairings.rs:760-857): lane 0 keeps the running point T
+// and computes each line (doubling_step / addition_step, serial: their Fp2 chains hardly parallelise), parks the triple in LDS
+// at lnw (54 limbs), five lanes evaluate it at P = pt and the whole wave multiplies it in.  q: the validated point (every lane
+// may hold it; lane 0's copy is used).  Result in WV_R.
+BN_HD inline void wide_miller_1(const Wide& W, const G2A& q, const Ws& pt, const Ws& lnw) {
+  BN_WIDE_PHASE(lane,
+    if (lane < 6u) fp2_store_mem(wide_val(W, WV_R, lane), lane == 0u ? fp2_one() : fp2_zero());
+  )
+  G2J T = {q.x, q.y, fp2_one()};
+  const Fp2 nqy = fp2_norm(fp2_neg(q.y));
+  const Fp2 g2 = fp2_const(bnc::GAMMA1[1]), g3 = fp2_const(bnc::GAMMA1[2]);
+  const Fp2 q1x = fp2_mul(fp2_norm(fp2_conj(q.x)), g2), q1y = fp2_mul(fp2_norm(fp2_conj(q.y)), g3);        // pi(Q)
+  const Fp2 q2x = fp2_mul(fp2_norm(fp2_conj(q1x)), g2);
+  const Fp2 q2y = fp2_norm(fp2_neg(fp2_mul(fp2_norm(fp2_conj(q1y)), g3)));                                  // -pi^2(Q)
+  for (int j = bnc::ATE_NAF_LEN - 2; j >= -2; --j) {                // j = -1, -2: the two Frobenius additions
+    if (j >= 0) {
+      wide_exec(W, WOP_MUL, WV_R, WV_R, WV_R);
+      BN_WIDE_PHASE(lane, if (lane == 0u) line_store(lnw, fp2_norm_line(doubling_step(T))); )
+      wide_line_eval_1<true>(W, WV_L, lnw, pt);
+      wide_exec(W, WOP_MUL, WV_R, WV_R, WV_L);
+    }
+    const int d = j >= 0 ? ate_naf_digit(j) : 1;
+    if (d != 0) {
+      const Fp2 ax = j >= 0 ? q.x : j == -1 ? q1x : q2x, ay = j >= 0 ? (d > 0 ? q.y : nqy) : j == -1 ? q1y : q2y;
+      BN_WIDE_PHASE(lane, if (lane == 0u) line_store(lnw, fp2_norm_line(addition_step(T, ax, ay))); )
+      wide_line_eval_1<true>(W, WV_L, lnw, pt);
+      wide_exec(W, WOP_MUL, WV_R, WV_R, WV_L);
+    }
+  }
+}
 // out = in^x by the addition chain of cyclotomic_exp_x_chain (pairing.h): 62 squarings + 17 products; R is the accumulator
 BN_HD inline void wide_exp_x(const Wide& W, uint32_t out, uint32_t in) {
   const ExpxOp prog[22] = {{-1, 1, -1, 1}, {-1, 1, -1, 2}, {-1, 1, -1, 3}, {-1, 1, 0, 4}, {-1, 0, 1, 5}, {-1, 0, 0, 6}, {3, 0, 4, 7},

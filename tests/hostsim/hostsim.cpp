@@ -177,6 +177,22 @@ int hs_miller_wide(const uint8_t* sig, const uint8_t* h, const uint8_t* pk, uint
   fp12_to_be(out + 1152, miller_loop_prepared(cw, ew));
   return 0;
 }
+// wide one-pair loop with a variable G2 point (lane 0 computes the lines) against miller_loop_1: out[0] wide, out[1] serial
+int hs_miller_wide_var(const uint8_t* g1, const uint8_t* g2, uint8_t* out) {
+  bool o1, o2;
+  G1A p = g1_decode(g1, o1);
+  G2A q = g2_decode(g2, o2);
+  if (!o1 || !o2) return 1;
+  std::vector<int32_t> lds(WIDE_LDS_DWORDS, 0), col(128, 0);
+  Wide W{lds.data()};
+  const Ws pt = {col.data(), 1, 0, false}, lnw = {col.data() + 32, 1, 0, false};
+  fp_store_mem(pt, fp_norm(p.x)); fp_store_mem(ws_at(pt, 9), fp_norm(p.y));
+  q.x = fp2_norm(q.x); q.y = fp2_norm(q.y);
+  wide_miller_1(W, q, pt, lnw);
+  fp12_to_be(out, wide_get(W, WV_R));
+  fp12_to_be(out + 384, miller_loop_1(p, q));
+  return 0;
+}
 void hs_pairing(const uint8_t* g1, const uint8_t* g2, uint8_t* out) {
   uint8_t st;
   Fp12 f = lane_miller_1(g1, g2, st);

@@ -254,3 +254,6 @@ def test_wide_miller_loops_over_prepared_keys(hs, oracle, pyref):
         w1, s1, w2, s2 = (out.raw[384 * k:384 * k + 384] for k in range(4))
         assert w1 == s1 == oracle.miller_loop_batch(h, pk, 1)
         assert w2 == s2
+        # variable G2 point: lane 0 computes the lines, the wave multiplies them in
+        assert hs.hs_miller_wide_var(h, pk, out) == 0
+        assert out.raw[:384] == out.raw[384:768] == oracle.miller_loop_batch(h, pk, 1)
