@@ -530,7 +530,7 @@ static int prepare_keys_async(blsbn254_ctx* c, const uint8_t* d_pks, const uint3
   HIPCHK(c, c->prep_raw.reserve(u * PREP_RAW_LIMBS * 4));
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-  LAUNCH2(c, "g2_prepare", k_g2_prepare, u, d_pks, d_keys, (uint32_t)u, (int32_t*)c->prep_raw.p, key_ok);
+  LAUNCH2(c, "g2_prepare", k_g2_prepare, 2 * 256 * (size_t)nblocks(u), d_pks, d_keys, (uint32_t)u, (int32_t*)c->prep_raw.p, key_ok);
   LAUNCH2(c, "g2_expand", k_g2_expand, u * (size_t)BN_NEG_G2_LINES, (const int32_t*)c->prep_raw.p, (uint32_t)u, table);
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
   return 0;
@@ -657,7 +657,7 @@ int blsbn254_g2_prepare_batch(blsbn254_ctx* c, const uint8_t* pks, size_t u, bls
   if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) { p->table.release(); p->raw.release(); p->ok.release(); delete p; return BLSBN254_E_NOMEM; }
   if (u) HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * u, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync((uint8_t*)c->in_a.p + 128 * u, NEG_G2_BYTES, 128, hipMemcpyHostToDevice, c->stream));
-  LAUNCH(c, "g2_prepare", k_g2_prepare, u1, (const uint8_t*)c->in_a.p, (const uint32_t*)nullptr, (uint32_t)u1, (int32_t*)p->raw.p, (uint8_t*)p->ok.p);
+  LAUNCH(c, "g2_prepare", k_g2_prepare, 2 * 256 * (size_t)nblocks(u1), (const uint8_t*)c->in_a.p, (const uint32_t*)nullptr, (uint32_t)u1, (int32_t*)p->raw.p, (uint8_t*)p->ok.p);
   LAUNCH(c, "g2_expand", k_g2_expand, u1 * (size_t)BN_NEG_G2_LINES, (const int32_t*)p->raw.p, (uint32_t)u1, (int32_t*)p->table.p);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *out = p;
@@ -1145,7 +1145,7 @@ static int aggregate_partial_impl(blsbn254_ctx* c, const uint8_t* pks, const uin
       HIPCHK(c, c->prep_table.reserve(64)); HIPCHK(c, c->prep_ok.reserve(u)); HIPCHK(c, c->prep_raw.reserve(u * PREP_RAW_LIMBS * 4));
       HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
       HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-      LAUNCH2(c, "g2_prepare", k_g2_prepare, u, (const uint8_t*)c->in_a.p, (const uint32_t*)c->kd_keys.p, (uint32_t)u, (int32_t*)c->prep_raw.p, (uint8_t*)c->prep_ok.p);
+      LAUNCH2(c, "g2_prepare", k_g2_prepare, 2 * 256 * (size_t)nblocks(u), (const uint8_t*)c->in_a.p, (const uint32_t*)c->kd_keys.p, (uint32_t)u, (int32_t*)c->prep_raw.p, (uint8_t*)c->prep_ok.p);
       HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
       LAUNCH(c, "kd_propagate", k_kd_propagate, np, (const uint32_t*)c->kd_rep.p, (uint32_t)np, (uint32_t)u, (uint32_t*)c->kd_kid.p, (uint32_t*)nullptr);   // no sorting here: no histogram
       prepared = true;
@@ -1272,7 +1272,7 @@ static int aggregate_verify_grouped(blsbn254_ctx* c, const uint8_t* pks, const u
   HIPCHK(c, c->prep_ok.reserve(np)); HIPCHK(c, c->prep_raw.reserve(np * PREP_RAW_LIMBS * 4));
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
   HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-  LAUNCH2(c, "g2_prepare", k_g2_prepare, np, (const uint8_t*)c->in_a.p, (const uint32_t*)c->kd_keys.p, (uint32_t)np, (int32_t*)c->prep_raw.p, (uint8_t*)c->prep_ok.p);
+  LAUNCH2(c, "g2_prepare", k_g2_prepare, 2 * 256 * (size_t)nblocks(np), (const uint8_t*)c->in_a.p, (const uint32_t*)c->kd_keys.p, (uint32_t)np, (int32_t*)c->prep_raw.p, (uint8_t*)c->prep_ok.p);
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
   // key ids, key-sorted order
   const size_t m1_max = n / G + u;

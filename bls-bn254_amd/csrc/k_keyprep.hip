@@ -119,16 +119,27 @@ __global__ void __launch_bounds__(256) k_kd_scatter(const uint32_t* kid, uint32_
 }
 // lines + validity of u keys.  keys == NULL: key k is pks[128 k]; else key k is the public key of tuple keys[k].
 // table: u x 88 x 54 limbs, key-major contiguous.
+// The two halves of the work -- the psi subgroup test and the 88 line steps -- are independent chains of about the same
+// length, and a launch over a few thousand keys is the latency of one lane: they run in DIFFERENT workgroups (the first
+// ceil(u / 256) workgroups compute lines, the next ceil(u / 256) validity), side by side instead of one after the other.
+// Launch with 2 * ceil(u / 256) workgroups of 256.
 BN_KERNEL k_g2_prepare(const uint8_t* pks, const uint32_t* keys, uint32_t u, int32_t* table, uint8_t* key_ok) {
-  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nb = (u + 255u) / 256u;
+  const bool check_role = blockIdx.x >= nb;
+  const uint32_t k = (check_role ? blockIdx.x - nb : blockIdx.x) * blockDim.x + threadIdx.x;
   if (k >= u) return;
   const uint8_t* b = pks + 128 * (size_t)(keys ? keys[k] : k);
   bool okd;
   G2A q = g2_decode(b, okd);
-  const bool ok = okd & !q.inf & g2_on_curve(q) & g2_torsion_free(q);
-  q.x = fp2_select(ok, q.x, fp2_const(bnc::G2_GEN_X)); q.y = fp2_select(ok, q.y, fp2_const(bnc::G2_GEN_Y)); q.inf = false;
-  g2_prepare_lines(q, Ws{table, 1, k * (uint32_t)(BN_NEG_G2_LINES * 54 * 4), true});
-  key_ok[k] = ok ? 1 : 0;
+  const bool curve_ok = okd & !q.inf & g2_on_curve(q);
+  if (check_role) {
+    key_ok[k] = (curve_ok & g2_torsion_free(q)) ? 1 : 0;
+  } else {
+    // a point that fails decoding / the curve equation is replaced by the generator (well-formed arithmetic; its table is never
+    // used: key_ok is 0); a point on the curve outside the subgroup runs the line steps as it is (likewise unused)
+    q.x = fp2_select(curve_ok, q.x, fp2_const(bnc::G2_GEN_X)); q.y = fp2_select(curve_ok, q.y, fp2_const(bnc::G2_GEN_Y)); q.inf = false;
+    g2_prepare_lines(q, Ws{table, 1, k * (uint32_t)(BN_NEG_G2_LINES * 54 * 4), true});
+  }
 }
 // The pair tables: lane (key k, step t) multiplies the key's line t with the fixed -G2gen line t (pairing.h line_pair_expand):
 // raw (u x 88 x 54 limbs) -> expanded (u x 88 x 162 limbs).  u x 88 lanes: the part of the preparation that is not sequential.
