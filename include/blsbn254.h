@@ -107,10 +107,15 @@ int blsbn254_aggregate_verify(blsbn254_ctx* ctx, const uint8_t* pks, const uint8
  * pairings.rs:609-660 (E6: 88 entries, not 68) -- beside hash-to-G1; the tuples then run a table-only Miller loop
  * (multi_miller_loop over prepared terms, pairings.rs:808-857) in key-sorted order.  Same bitmap as the exact
  * per-tuple path, which batches of mostly distinct keys keep taking.  BLSBN254_AUTO_PREPARE=0 in the environment or
- * blsbn254_set_auto_prepare(ctx, 0) forces the exact path; blsbn254_path_stats counts the chunks each path served. */
+ * blsbn254_set_auto_prepare(ctx, 0) forces the exact path; blsbn254_path_stats counts the chunks each path served.
+ * Small calls.  A launch of at most 4096 tuples is bound by the latency of one lane's chain, so such calls (verify, pairing,
+ * Miller loop, final exponentiation, aggregate verify) run the Miller loop and the hard part of the final exponentiation
+ * with one WAVE per tuple (same values, same bytes), and verify chunks of that size take the prepared-key path whatever
+ * their keys (the tables are what that Miller loop reads).  BLSBN254_WIDE_FE=0 switches this off,
+ * BLSBN254_WIDE_FE_MAX=<n> moves the limit. */
 int blsbn254_set_auto_prepare(blsbn254_ctx* ctx, int on);
 int blsbn254_path_stats(blsbn254_ctx* ctx, uint64_t out[2] /* prepared, exact */);
-/* blsbn254_aggregate_verify over repeated keys (same rule: at most half of the n keys distinct, n >= 1024, auto-prepare on):
+/* blsbn254_aggregate_verify over repeated keys (auto-prepare on; at most half of the n >= 1024 keys distinct, or at most 4095 pairs):
  * by bilinearity in the first argument  prod_{i: pk_i = pk} e(H(msg_i), pk) = e(sum_i H(msg_i), pk)  -- exact, no randomness --
  * the H(msg_i) of every distinct key are summed in G1 (n additions) and ONE Miller loop per distinct key runs
  * (multi_miller_loop over u + 1 prepared terms, pairings.rs:808-857).  Same boolean; the Miller value differs from the product
