@@ -42,9 +42,14 @@ struct blsbn254_ctx {
   // RLC over repeated keys (k_rlc2.hip): weighted points, chunk descriptions, virtual tuples, fallback list
   DevBuf r2_seed, r2_a, r2_b, r2_sigok, r2_tchunk, r2_ccnt, r2_cbase, r2_ckid, r2_cstart, r2_clen, r2_csig, r2_ch, r2_cstate, r2_iota, r2_cisone,
          r2_need, r2_bcnt, r2_bbase, r2_list, r2_valid;
+  DevBuf ks_cnt[2], ks_base[2], ks_kid[2], ks_start, ks_len, ks_tchunk, ks_iota, ks_out[2], ks_out2[2];   // key_sums scratch (levels of chunk sums)
+  DevBuf r2_sa, r2_sb, r2_celig, r2_kelig, r2_ksig, r2_kh, r2_kstate, r2_kisone, r2_kpass, r2_cpass, r2_clist, r2_cneed, r2_cbcnt, r2_cbbase;   // chunk sums, key round of the RLC path
+  bool rlc_key_round = true;         // RLC: first check every key's whole run as ONE virtual tuple (BLSBN254_RLC_KEY_ROUND=0 disables)
+  unsigned rlc_key_skip = 0, rlc_key_streak = 0;   // ... backing off while batches keep failing it (skip the next 2, 4, 8, 16 chunks of work)
   size_t rlc_group = 16;             // tuples per chunk (BLSBN254_RLC_GROUP / blsbn254_set_rlc_group)
   bool rlc_group_auto = true;        // no explicit setting: 16, raised (to at most 32) when that saves a whole round of waves
   size_t lanes_per_round = 65536;    // CUs x 256: the lanes resident at one wave per SIMD (the big kernels' occupancy)
+  uint64_t stat_rlc_key_rounds = 0, stat_rlc_key_rounds_passed = 0;
   uint64_t stat_rlc[4] = {0, 0, 0, 0};   // tuples on the chunked path, chunks checked, tuples sent to the exact fallback, tuples on the exact path (distinct keys)
   DevBuf status_all;     // per-element decode status of a chunked call, all chunks
   // prepared-key verify path (k_keyprep.hip, k_miller_prep.hip)
@@ -150,6 +155,7 @@ int blsbn254_ctx_create(int device, blsbn254_ctx** out) {
   if (const char* e = std::getenv("BLSBN254_AUTO_PREPARE")) c->auto_prepare = std::atoi(e) != 0;
   if (const char* e = std::getenv("BLSBN254_RLC_GROUP")) { long v = std::atol(e); if (v >= 2 && v <= 4096) { c->rlc_group = (size_t)v; c->rlc_group_auto = false; } }
   c->lanes_per_round = (size_t)prop.multiProcessorCount * 256;
+  if (const char* e = std::getenv("BLSBN254_RLC_KEY_ROUND")) c->rlc_key_round = std::atoi(e) != 0;
   if (const char* e = std::getenv("BLSBN254_WIDE_FE")) c->wide_fe = std::atoi(e) != 0;
   if (const char* e = std::getenv("BLSBN254_WIDE_FE_MAX")) { long v = std::atol(e); if (v >= 0 && v <= (1 << 20)) c->wide_fe_max = (size_t)v; }
   *out = c;
@@ -171,7 +177,10 @@ void blsbn254_ctx_destroy(blsbn254_ctx* c) {
                     &c->prep_isone, &c->prep_valid};
     for (DevBuf* b : kb) b->release(); }
   { DevBuf* rb[] = {&c->r2_seed, &c->r2_a, &c->r2_b, &c->r2_sigok, &c->r2_tchunk, &c->r2_ccnt, &c->r2_cbase, &c->r2_ckid, &c->r2_cstart, &c->r2_clen, &c->r2_csig,
-                    &c->r2_ch, &c->r2_cstate, &c->r2_iota, &c->r2_cisone, &c->r2_need, &c->r2_bcnt, &c->r2_bbase, &c->r2_list, &c->r2_valid};
+                    &c->r2_ch, &c->r2_cstate, &c->r2_iota, &c->r2_cisone, &c->r2_need, &c->r2_bcnt, &c->r2_bbase, &c->r2_list, &c->r2_valid,
+                    &c->ks_cnt[0], &c->ks_cnt[1], &c->ks_base[0], &c->ks_base[1], &c->ks_kid[0], &c->ks_kid[1], &c->ks_start, &c->ks_len, &c->ks_tchunk, &c->ks_iota,
+                    &c->ks_out[0], &c->ks_out[1], &c->ks_out2[0], &c->ks_out2[1], &c->r2_sa, &c->r2_sb, &c->r2_celig, &c->r2_kelig, &c->r2_ksig, &c->r2_kh, &c->r2_kstate, &c->r2_kisone,
+                    &c->r2_kpass, &c->r2_cpass, &c->r2_clist, &c->r2_cneed, &c->r2_cbcnt, &c->r2_cbbase};
     for (DevBuf* b : rb) b->release(); }
   (void)hipStreamSynchronize(c->stream2);
   (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join);
@@ -813,6 +822,51 @@ int blsbn254_aggregate_path_stats(blsbn254_ctx* c, uint64_t out[2]) {
 }
 int blsbn254_set_auto_prepare(blsbn254_ctx* c, int on) { if (!c) return BLSBN254_E_ARG; c->auto_prepare = on != 0; return 0; }
 
+// ---------------- sums of G1 points per key
+// `items` homogeneous points (limb-major at pts, stride pts_stride; optionally a second array pts2 summed alongside) are grouped
+// by key in key order: item j has key kid[mark_perm[j]] and is the point in column pt_perm[j] (or j when pt_perm is NULL); key k
+// owns hist[k] consecutive items ending at run_end[k].  Level by level, runs are cut into chunks of at most KEY_SUM_GROUP items,
+// every chunk is summed by one lane, and the chunk sums (in key order too) are the items of the next level, until every key has
+// ONE sum: *out / *out2 (stride u), indexed by key id.  One host synchronisation per level (the chunk count).
+static const size_t KEY_SUM_GROUP = 32;
+static int key_sums(blsbn254_ctx* c, const int32_t* pts, const int32_t* pts2, size_t pts_stride, const uint32_t* mark_perm, const uint32_t* pt_perm,
+                    const uint32_t* kid, const uint32_t* hist, const uint32_t* run_end, size_t items, size_t u, const int32_t** out, const int32_t** out2) {
+  const size_t G = KEY_SUM_GROUP, m_max = items / G + u;
+  const uint32_t u32 = (uint32_t)u, G32 = (uint32_t)G;
+  for (int t = 0; t < 2; ++t) {
+    HIPCHK(c, c->ks_cnt[t].reserve(4 * (u + 2))); HIPCHK(c, c->ks_base[t].reserve(4 * (u + 2))); HIPCHK(c, c->ks_kid[t].reserve(4 * m_max));
+    HIPCHK(c, c->ks_out[t].reserve(27 * 4 * m_max));
+    if (pts2) HIPCHK(c, c->ks_out2[t].reserve(27 * 4 * m_max));
+  }
+  HIPCHK(c, c->ks_start.reserve(4 * m_max)); HIPCHK(c, c->ks_len.reserve(4 * m_max)); HIPCHK(c, c->ks_tchunk.reserve(4 * items)); HIPCHK(c, c->ks_iota.reserve(4 * m_max));
+  LAUNCH(c, "iota", k_iota_u32, m_max, (uint32_t*)c->ks_iota.p, (uint32_t)m_max);
+  int a = 0;
+  for (int level = 0; ; ++level) {
+    if (level > 8) { c->last_error = "internal: key sums do not converge"; return BLSBN254_E_HIP; }
+    uint32_t *cnt = (uint32_t*)c->ks_cnt[a].p, *base = (uint32_t*)c->ks_base[a].p, *ckid = (uint32_t*)c->ks_kid[a].p;
+    LAUNCH(c, "rlc2_counts", k_rlc2_chunk_counts, u + 1, hist, u32, G32, cnt);
+    { ProfScope ps_(c, "kd_scan"); hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)cnt, u32 + 1, base); }
+    HIPCHK(c, hipGetLastError());
+    uint32_t m32 = 0;
+    HIPCHK(c, hipMemcpyAsync(&m32, base + u, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t m = m32;
+    if (m < u || m > m_max || m > items) { c->last_error = "internal: chunk count out of range"; return BLSBN254_E_HIP; }
+    LAUNCH(c, "rlc2_mark", k_rlc2_mark, items, mark_perm, kid, hist, run_end, (const uint32_t*)base, (uint32_t)items, G32,
+           (uint32_t*)c->ks_tchunk.p, ckid, (uint32_t*)c->ks_start.p, (uint32_t*)c->ks_len.p);
+    LAUNCH(c, "g1_seg_sum", k_g1_seg_sum, m, pts, pts_stride, pt_perm, (const uint32_t*)c->ks_start.p, (const uint32_t*)c->ks_len.p, m, (int32_t*)c->ks_out[a].p, m);
+    if (pts2) { LAUNCH(c, "g1_seg_sum", k_g1_seg_sum, m, pts2, pts_stride, pt_perm, (const uint32_t*)c->ks_start.p, (const uint32_t*)c->ks_len.p, m, (int32_t*)c->ks_out2[a].p, m); }
+    pts = (const int32_t*)c->ks_out[a].p; pts2 = pts2 ? (const int32_t*)c->ks_out2[a].p : nullptr; pts_stride = m; items = m;
+    if (m == u) break;                                                          // one chunk per key: chunk index == key id
+    // next level: item j has key ckid[j]; key k owns items base[k] .. base[k + 1]
+    mark_perm = (const uint32_t*)c->ks_iota.p; pt_perm = nullptr; kid = ckid; hist = cnt; run_end = base + 1;
+    a ^= 1;
+  }
+  *out = pts;
+  if (out2) *out2 = pts2;
+  return 0;
+}
+
 // ---------------- random-linear-combination batch verification over repeated keys (k_rlc2.hip)
 static int draw_seed(blsbn254_ctx* c, uint8_t out[32]) {
   size_t got = 0;
@@ -891,23 +945,81 @@ static int rlc2_chunk_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* 
   HIPCHK(c, c->r2_ch.reserve(27 * 4 * m)); HIPCHK(c, c->r2_cstate.reserve(m)); HIPCHK(c, c->r2_iota.reserve(4 * m)); HIPCHK(c, c->r2_cisone.reserve(m));
   LAUNCH(c, "rlc2_mark", k_rlc2_mark, n, (const uint32_t*)perm, (const uint32_t*)kid, (const uint32_t*)hist, (const uint32_t*)cursor, (const uint32_t*)cbase, n32, G32,
          (uint32_t*)c->r2_tchunk.p, (uint32_t*)c->r2_ckid.p, (uint32_t*)c->r2_cstart.p, (uint32_t*)c->r2_clen.p);
+  HIPCHK(c, c->r2_sa.reserve(27 * 4 * m)); HIPCHK(c, c->r2_sb.reserve(27 * 4 * m)); HIPCHK(c, c->r2_celig.reserve(4 * m));
   LAUNCH(c, "rlc2_sum", k_rlc2_sum, m, (const int32_t*)c->r2_a.p, (const int32_t*)c->r2_b.p, n, (const uint8_t*)c->r2_sigok.p, (const uint32_t*)c->r2_cstart.p,
-         (const uint32_t*)c->r2_clen.p, m, (uint8_t*)c->r2_csig.p, (int32_t*)c->r2_ch.p, (uint8_t*)c->r2_cstate.p);
-  LAUNCH(c, "iota", k_iota_u32, m, (uint32_t*)c->r2_iota.p, (uint32_t)m);
+         (const uint32_t*)c->r2_clen.p, m, (int32_t*)c->r2_sa.p, (int32_t*)c->r2_sb.p, (uint32_t*)c->r2_celig.p);
   HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));                      // the key tables are ready
-  // the chunk round: every chunk is one virtual tuple on the prepared-key verify path
-  rc = prepared_round(c, (const uint32_t*)c->r2_iota.p, (const uint32_t*)c->r2_ckid.p, (const uint8_t*)c->r2_csig.p, (const int32_t*)c->r2_ch.p, m, m, (uint8_t*)c->r2_cisone.p);
+  // The key round: ALL tuples of a key as one virtual tuple (the chunk sums of the key, summed) -- u checks, few enough for the
+  // wave-per-tuple kernels.  A batch without invalid signatures (the usual case) is decided here, in a fraction of a chunk round;
+  // otherwise only the chunks of the keys that failed are looked at below.  Same weights, hence the same 2^-64 bound per check.
+  const size_t mblk = (m + 255) / 256;
+  HIPCHK(c, c->r2_cpass.reserve(m)); HIPCHK(c, c->r2_clist.reserve(4 * m)); HIPCHK(c, c->r2_cneed.reserve(m)); HIPCHK(c, c->r2_cbcnt.reserve(4 * (mblk + 2)));
+  HIPCHK(c, c->r2_cbbase.reserve(4 * (mblk + 2)));
+  const uint32_t* clist = nullptr;                     // chunks of the chunk round (NULL: all of them, in order)
+  size_t mc = m;
+  LAUNCH(c, "iota", k_iota_u32, m, (uint32_t*)c->r2_iota.p, (uint32_t)m);
+  // Batches that keep failing it (a stream with invalid signatures spread over all keys) would pay for the key round every time:
+  // after a failure the next 2 (then 4, 8, 16) batches skip it; a pass resets the back-off.
+  const bool key_round = c->rlc_key_round && c->rlc_key_skip == 0;
+  if (c->rlc_key_round && c->rlc_key_skip) --c->rlc_key_skip;
+  if (key_round) {
+    HIPCHK(c, c->r2_kelig.reserve(4 * u)); HIPCHK(c, c->r2_ksig.reserve(64 * u)); HIPCHK(c, c->r2_kh.reserve(27 * 4 * u)); HIPCHK(c, c->r2_kstate.reserve(u));
+    HIPCHK(c, c->r2_kisone.reserve(u)); HIPCHK(c, c->r2_kpass.reserve(u)); HIPCHK(c, c->misc.reserve(64));
+    const int32_t *ksa = nullptr, *ksb = nullptr;
+    rc = key_sums(c, (const int32_t*)c->r2_sa.p, (const int32_t*)c->r2_sb.p, m, (const uint32_t*)c->r2_iota.p, nullptr, (const uint32_t*)c->r2_ckid.p,
+                  (const uint32_t*)ccnt, (const uint32_t*)cbase + 1, m, u, &ksa, &ksb);
+    if (rc) return rc;
+    HIPCHK(c, hipMemsetAsync(c->r2_kelig.p, 0, 4 * u, c->stream));
+    LAUNCH(c, "rlc2_key_elig", k_rlc2_key_elig, m, (const uint32_t*)c->r2_ckid.p, (const uint32_t*)c->r2_celig.p, (uint32_t)m, (uint32_t*)c->r2_kelig.p);
+    LAUNCH(c, "rlc2_virtual", k_rlc2_virtual, u, ksa, ksb, u, (const uint32_t*)c->r2_kelig.p, (const uint32_t*)nullptr, u, (uint8_t*)c->r2_ksig.p, (int32_t*)c->r2_kh.p,
+           (uint8_t*)c->r2_kstate.p);
+    rc = prepared_round(c, (const uint32_t*)c->r2_iota.p, (const uint32_t*)c->r2_iota.p, (const uint8_t*)c->r2_ksig.p, (const int32_t*)c->r2_kh.p, u, u, (uint8_t*)c->r2_kisone.p);
+    if (rc) return rc;
+    int* d_all = (int*)c->misc.p;
+    static const int one_i = 1;
+    HIPCHK(c, hipMemcpyAsync(d_all, &one_i, 4, hipMemcpyHostToDevice, c->stream));
+    LAUNCH(c, "rlc2_keys_pass", k_rlc2_keys_pass, u, (const uint8_t*)c->prep_ok.p, (const uint8_t*)c->r2_kstate.p, (const uint8_t*)c->r2_kisone.p, u32, (uint8_t*)c->r2_kpass.p, d_all);
+    // the chunks of the keys that failed, as an ordered list (counted while the host waits for the verdict)
+    LAUNCH(c, "rlc2_chunk_need", k_rlc2_chunk_need, m, (const uint32_t*)c->r2_ckid.p, (const uint8_t*)c->r2_kpass.p, (uint32_t)m, (uint8_t*)c->r2_cneed.p, (uint32_t*)c->r2_cbcnt.p);
+    { ProfScope ps_(c, "kd_scan"); hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)c->r2_cbcnt.p, (uint32_t)mblk + 1, (uint32_t*)c->r2_cbbase.p); }
+    HIPCHK(c, hipGetLastError());
+    int all_pass = 0; uint32_t mc32 = 0;
+    HIPCHK(c, hipMemcpyAsync(&all_pass, d_all, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&mc32, (uint32_t*)c->r2_cbbase.p + mblk, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->stat_rlc[0] += n; ++c->stat_rlc_key_rounds;
+    if (all_pass == 1) {
+      ++c->stat_rlc_key_rounds_passed;
+      c->rlc_key_streak = 0;
+      LAUNCH(c, "rlc2_valid_fast", k_rlc2_valid_fast, n, (const uint32_t*)perm, (const uint32_t*)kid, (const uint8_t*)c->r2_sigok.p, (const uint8_t*)c->prep_ok.p, n32, (uint8_t*)c->r2_valid.p);
+      LAUNCH(c, "pack_bitmap", k_pack_bitmap, n, (const uint8_t*)c->r2_valid.p, n, d_bitmap);
+      return 0;
+    }
+    if (c->rlc_key_streak < 4) ++c->rlc_key_streak;
+    c->rlc_key_skip = 1u << c->rlc_key_streak;
+    if (mc32 == 0 || mc32 > m) { c->last_error = "internal: chunk list out of range"; return BLSBN254_E_HIP; }
+    mc = mc32;
+    LAUNCH(c, "rlc2_compact", k_rlc2_compact, m, (const uint8_t*)c->r2_cneed.p, (const uint32_t*)c->r2_iota.p, (uint32_t)m, (const uint32_t*)c->r2_cbbase.p, (uint32_t*)c->r2_clist.p);
+    clist = (const uint32_t*)c->r2_clist.p;
+    HIPCHK(c, hipMemsetAsync(c->r2_cpass.p, 1, m, c->stream));               // chunks of the keys that passed
+  } else {
+    c->stat_rlc[0] += n;
+  }
+  // the chunk round: every (listed) chunk is one virtual tuple on the prepared-key verify path
+  LAUNCH(c, "rlc2_virtual", k_rlc2_virtual, mc, (const int32_t*)c->r2_sa.p, (const int32_t*)c->r2_sb.p, m, (const uint32_t*)c->r2_celig.p, clist, mc, (uint8_t*)c->r2_csig.p,
+         (int32_t*)c->r2_ch.p, (uint8_t*)c->r2_cstate.p);
+  rc = prepared_round(c, clist ? clist : (const uint32_t*)c->r2_iota.p, (const uint32_t*)c->r2_ckid.p, (const uint8_t*)c->r2_csig.p, (const int32_t*)c->r2_ch.p, m, mc, (uint8_t*)c->r2_cisone.p);
   if (rc) return rc;
+  LAUNCH(c, "rlc2_chunk_pass", k_rlc2_chunk_pass, mc, clist, (const uint8_t*)c->r2_cstate.p, (const uint8_t*)c->r2_cisone.p, (const uint8_t*)c->flags.p, (uint32_t)mc, (uint8_t*)c->r2_cpass.p);
   LAUNCH(c, "rlc2_resolve", k_rlc2_resolve, n, (const uint32_t*)perm, (const uint32_t*)kid, (const uint32_t*)c->r2_tchunk.p, (const uint8_t*)c->r2_sigok.p,
-         (const uint8_t*)c->prep_ok.p, (const uint8_t*)c->r2_cstate.p, (const uint8_t*)c->r2_cisone.p, (const uint8_t*)c->flags.p, n32, (uint8_t*)c->r2_valid.p,
-         (uint8_t*)c->r2_need.p, (uint32_t*)c->r2_bcnt.p);
+         (const uint8_t*)c->prep_ok.p, (const uint8_t*)c->r2_cpass.p, n32, (uint8_t*)c->r2_valid.p, (uint8_t*)c->r2_need.p, (uint32_t*)c->r2_bcnt.p);
   { ProfScope ps_(c, "kd_scan"); hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)c->r2_bcnt.p, (uint32_t)nblk + 1, (uint32_t*)c->r2_bbase.p); }
   HIPCHK(c, hipGetLastError());
   uint32_t m2 = 0;
   HIPCHK(c, hipMemcpyAsync(&m2, (uint32_t*)c->r2_bbase.p + nblk, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (m2 > n) { c->last_error = "internal: fallback count out of range"; return BLSBN254_E_HIP; }
-  c->stat_rlc[0] += n; c->stat_rlc[1] += m; c->stat_rlc[2] += m2;
+  c->stat_rlc[1] += mc; c->stat_rlc[2] += m2;
   if (m2) {                                                                     // eligible tuples of failed chunks: the exact prepared-key path
     HIPCHK(c, c->prep_isone.reserve(m2));
     LAUNCH(c, "rlc2_compact", k_rlc2_compact, n, (const uint8_t*)c->r2_need.p, (const uint32_t*)perm, n32, (const uint32_t*)c->r2_bbase.p, (uint32_t*)c->r2_list.p);
@@ -958,11 +1070,13 @@ int blsbn254_set_rlc_group(blsbn254_ctx* c, size_t group) {
   c->rlc_group_auto = group == 0;
   return 0;
 }
-int blsbn254_rlc_stats(blsbn254_ctx* c, uint64_t out[4]) {
+int blsbn254_rlc_stats(blsbn254_ctx* c, uint64_t out[6]) {
   if (!c || !out) return BLSBN254_E_ARG;
   for (int k = 0; k < 4; ++k) out[k] = c->stat_rlc[k];
+  out[4] = c->stat_rlc_key_rounds; out[5] = c->stat_rlc_key_rounds_passed;
   return 0;
 }
+int blsbn254_set_rlc_key_round(blsbn254_ctx* c, int on) { if (!c) return BLSBN254_E_ARG; c->rlc_key_round = on != 0; c->rlc_key_skip = c->rlc_key_streak = 0; return 0; }
 
 // ---------------- random-linear-combination batch verification
 static const size_t RLC_GROUP = 16;      // distinct-key variant: tuples per shared final exponentiation (power of two)
@@ -1239,11 +1353,10 @@ int blsbn254_aggregate_finish(blsbn254_ctx* c, const uint8_t* partials, size_t k
 // Aggregate verify over a batch that repeats public keys, by bilinearity in the first argument (exact, no randomness):
 //   prod_i e(H_i, pk_(k_i)) = prod_k e( sum_{i: k_i = k} H_i , pk_k )
 // so only one Miller loop per DISTINCT key (plus the signature's pair) runs, after n G1 additions: key de-duplication and
-// key-sorted order as in verify_batch, the sums by levels of chunks of AGG_SUM_GROUP points (k_g1_seg_sum), the u + 1 pairs on the
+// key-sorted order as in verify_batch, the sums by levels of chunks of KEY_SUM_GROUP points (key_sums, k_g1_seg_sum), the u + 1 pairs on the
 // prepared two-pairs-per-lane loop, product tree, ONE final exponentiation.  The boolean is aggregate_verify's; the Miller
 // value is not the product of the n per-pair values (blsbn254_aggregate_partial keeps that bit-exact form for the sharded API).
 // *took = false: keys do not repeat, nothing was done.
-static const size_t AGG_SUM_GROUP = 32;
 static int aggregate_verify_grouped(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t agg_sig[64],
                                     const uint8_t* dst, size_t dst_len, int* valid, bool* took) {
   *took = false;
@@ -1263,8 +1376,8 @@ static int aggregate_verify_grouped(blsbn254_ctx* c, const uint8_t* pks, const u
   const bool small = c->wide_fe && n + 1 <= c->wide_fe_max;       // few pairs: from tables, one wave per pair, whatever the keys
   if (!((u * 2 <= n || small) && u + 1 <= PREP_MAX_KEYS)) return 0;
   *took = true;
-  const size_t G = AGG_SUM_GROUP, np = u + 1, n_lanes = (np + 1) / 2;
-  const uint32_t n32 = (uint32_t)n, u32 = (uint32_t)u, G32 = (uint32_t)G;
+  const size_t np = u + 1, n_lanes = (np + 1) / 2;
+  const uint32_t n32 = (uint32_t)n, u32 = (uint32_t)u;
   // the u keys and -G2gen (key id u) become line tables on the second stream, beside the hashing
   const uint32_t last_key = n32;
   HIPCHK(c, hipMemcpyAsync((uint32_t*)c->kd_keys.p + u, &last_key, 4, hipMemcpyHostToDevice, c->stream));
@@ -1275,11 +1388,7 @@ static int aggregate_verify_grouped(blsbn254_ctx* c, const uint8_t* pks, const u
   LAUNCH2(c, "g2_prepare", k_g2_prepare, 2 * 256 * (size_t)nblocks(np), (const uint8_t*)c->in_a.p, (const uint32_t*)c->kd_keys.p, (uint32_t)np, (int32_t*)c->prep_raw.p, (uint8_t*)c->prep_ok.p);
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
   // key ids, key-sorted order
-  const size_t m1_max = n / G + u;
-  HIPCHK(c, c->h_ws.reserve(n * 27 * 4)); HIPCHK(c, c->kd_cursor.reserve(4 * (u + 1))); HIPCHK(c, c->kd_perm.reserve(4 * n)); HIPCHK(c, c->r2_tchunk.reserve(4 * n));
-  HIPCHK(c, c->r2_ccnt.reserve(4 * (u + 2))); HIPCHK(c, c->r2_cbase.reserve(4 * (u + 2))); HIPCHK(c, c->r2_bcnt.reserve(4 * (u + 2))); HIPCHK(c, c->r2_bbase.reserve(4 * (u + 2)));
-  HIPCHK(c, c->r2_ckid.reserve(4 * m1_max)); HIPCHK(c, c->r2_list.reserve(4 * m1_max)); HIPCHK(c, c->r2_cstart.reserve(4 * m1_max)); HIPCHK(c, c->r2_clen.reserve(4 * m1_max));
-  HIPCHK(c, c->r2_iota.reserve(4 * m1_max)); HIPCHK(c, c->r2_a.reserve(27 * 4 * m1_max)); HIPCHK(c, c->r2_b.reserve(27 * 4 * m1_max));
+  HIPCHK(c, c->h_ws.reserve(n * 27 * 4)); HIPCHK(c, c->kd_cursor.reserve(4 * (u + 1))); HIPCHK(c, c->kd_perm.reserve(4 * n));
   HIPCHK(c, c->f_ws.reserve(n_lanes * 108 * 4)); HIPCHK(c, c->flags.reserve(np)); HIPCHK(c, c->status.reserve(np + 8)); HIPCHK(c, c->misc.reserve(64));
   HIPCHK(c, c->rlc_b.reserve(np * 18 * 4)); HIPCHK(c, c->rlc_idx.reserve(4 * np));
   uint32_t *hist = (uint32_t*)c->kd_hist.p, *cursor = (uint32_t*)c->kd_cursor.p, *perm = (uint32_t*)c->kd_perm.p, *kid = (uint32_t*)c->kd_kid.p;
@@ -1289,35 +1398,10 @@ static int aggregate_verify_grouped(blsbn254_ctx* c, const uint8_t* pks, const u
   HIPCHK(c, hipGetLastError());
   LAUNCH(c, "kd_scatter", k_kd_scatter, n, (const uint32_t*)kid, n32, u32, cursor, perm);          // cursor[k] is now the END of run k
   LAUNCH(c, "hash_to_g1", k_hash_to_g1, n, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p, n, (const uint8_t*)c->dst.p, dl, (int32_t*)c->h_ws.p, n, (uint8_t*)nullptr, 3);
-  LAUNCH(c, "iota", k_iota_u32, m1_max, (uint32_t*)c->r2_iota.p, (uint32_t)m1_max);
-  // sums per key, level by level: items (level 0: the tuples in sorted order; later: the chunk sums of the level before, which
-  // are in key order too) -> chunks of at most G items of one key -> one sum per chunk, until every key has ONE chunk
-  const int32_t* pts = (const int32_t*)c->h_ws.p; size_t pts_stride = n; const uint32_t* it_perm = perm; const uint32_t* it_kid = kid;
-  const uint32_t* it_hist = hist; const uint32_t* it_end = cursor;
-  uint32_t *cnt_a = (uint32_t*)c->r2_ccnt.p, *base_a = (uint32_t*)c->r2_cbase.p, *cnt_b = (uint32_t*)c->r2_bcnt.p, *base_b = (uint32_t*)c->r2_bbase.p;
-  uint32_t *ckid_a = (uint32_t*)c->r2_ckid.p, *ckid_b = (uint32_t*)c->r2_list.p;
-  int32_t *out_a = (int32_t*)c->r2_a.p, *out_b = (int32_t*)c->r2_b.p;
-  size_t items = n;
-  for (int level = 0; ; ++level) {
-    if (level > 8) { c->last_error = "internal: key sums do not converge"; return BLSBN254_E_HIP; }
-    LAUNCH(c, "rlc2_counts", k_rlc2_chunk_counts, u + 1, it_hist, u32, G32, cnt_a);
-    { ProfScope ps_(c, "kd_scan"); hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, c->stream, (const uint32_t*)cnt_a, u32 + 1, base_a); }
-    HIPCHK(c, hipGetLastError());
-    uint32_t m32 = 0;
-    HIPCHK(c, hipMemcpyAsync(&m32, base_a + u, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const size_t m = m32;
-    if (m < u || m > m1_max || m > items) { c->last_error = "internal: chunk count out of range"; return BLSBN254_E_HIP; }
-    LAUNCH(c, "rlc2_mark", k_rlc2_mark, items, it_perm, it_kid, it_hist, it_end, (const uint32_t*)base_a, (uint32_t)items, G32,
-           (uint32_t*)c->r2_tchunk.p, ckid_a, (uint32_t*)c->r2_cstart.p, (uint32_t*)c->r2_clen.p);
-    LAUNCH(c, "g1_seg_sum", k_g1_seg_sum, m, pts, pts_stride, level == 0 ? (const uint32_t*)perm : (const uint32_t*)nullptr, (const uint32_t*)c->r2_cstart.p,
-           (const uint32_t*)c->r2_clen.p, m, out_a, m);
-    pts = out_a; pts_stride = m; items = m;
-    if (m == u) break;                                                          // one chunk per key: chunk index == key id
-    // next level: item j has key ckid_a[j]; key k owns items base_a[k] .. base_a[k + 1]
-    it_perm = (const uint32_t*)c->r2_iota.p; it_kid = ckid_a; it_hist = cnt_a; it_end = base_a + 1;
-    std::swap(cnt_a, cnt_b); std::swap(base_a, base_b); std::swap(ckid_a, ckid_b); std::swap(out_a, out_b);
-  }
+  // sums per key: the tuples in sorted order (columns perm[s] of h_ws) -> one sum per key (key_sums)
+  const int32_t* pts = nullptr; size_t pts_stride = u;
+  rc = key_sums(c, (const int32_t*)c->h_ws.p, nullptr, n, perm, perm, kid, hist, cursor, n, u, &pts, nullptr);
+  if (rc) return rc;
   // the u + 1 pairs: (sum_k, pk_k) for k < u and (agg_sig, -G2gen) as pair u with key id u
   int32_t* h2 = (int32_t*)c->rlc_b.p; uint8_t* st = (uint8_t*)c->status.p; uint32_t* kid2 = (uint32_t*)c->rlc_idx.p;
   int* d_ok = (int*)c->misc.p;                                                  // [0] all keys valid, [1] (byte) signature valid, [4] is_one

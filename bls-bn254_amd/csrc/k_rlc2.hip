@@ -89,10 +89,9 @@ __global__ void k_rlc2_mark(const uint32_t* perm, const uint32_t* kid, const uin
   tuple_chunk[s] = c;
   if (pos % G == 0) { chunk_kid[c] = k; chunk_start[c] = s; chunk_len[c] = cnt - pos < G ? cnt - pos : G; }
 }
-// One lane per chunk: the virtual tuple (sum A_s as 64 signature bytes, sum B_s homogeneous with stride m).
-// state: 0 = no eligible member (nothing to check), 1 = check the virtual tuple, 2 = degenerate sum (treated as a failed chunk).
+// One lane per chunk: the sums of the chunk's weighted points (homogeneous, stride m) and the number of eligible members.
 BN_KERNEL k_rlc2_sum(const int32_t* a_ws, const int32_t* b_ws, size_t n, const uint8_t* sig_ok, const uint32_t* chunk_start, const uint32_t* chunk_len,
-                     size_t m, uint8_t* c_sig, int32_t* c_h, uint8_t* c_state) {
+                     size_t m, int32_t* sa_ws, int32_t* sb_ws, uint32_t* elig_out) {
   const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= m) return;
   const size_t s0 = chunk_start[c];
@@ -105,14 +104,62 @@ BN_KERNEL k_rlc2_sum(const int32_t* a_ws, const int32_t* b_ws, size_t n, const u
     B = proj_add(B, load_g1p(b_ws + s0 + j, n));
     elig += sig_ok[s0 + j];
   }
+  store_g1p(sa_ws + c, m, A); store_g1p(sb_ws + c, m, B);
+  elig_out[c] = elig;
+}
+// key_elig[k] += eligible members of every chunk of key k (key_elig zeroed by the host)
+__global__ void k_rlc2_key_elig(const uint32_t* chunk_kid, const uint32_t* chunk_elig, uint32_t m, uint32_t* key_elig) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < m && chunk_elig[c]) atomicAdd(&key_elig[chunk_kid[c]], chunk_elig[c]);
+}
+// The virtual tuple of a group (a chunk, or all tuples of a key): sum A as 64 signature bytes, sum B homogeneous (stride cnt).
+// state: 0 = no eligible member (nothing to check), 1 = check the virtual tuple, 2 = degenerate sum (treated as failed).
+BN_KERNEL k_rlc2_virtual(const int32_t* sa_ws, const int32_t* sb_ws, size_t stride, const uint32_t* elig, const uint32_t* list, size_t cnt,
+                         uint8_t* c_sig, int32_t* c_h, uint8_t* c_state) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cnt) return;
+  const size_t c = list ? list[j] : j;                 // with a list: only the listed groups, each written at its own index
+  G1P A = load_g1p(sa_ws + c, stride), B = load_g1p(sb_ws + c, stride);
   const bool degenerate = fp_is_zero(A.z) | fp_is_zero(B.z);
-  const bool live = elig != 0 && !degenerate;
+  const bool live = elig[c] != 0 && !degenerate;
   G1A gp; gp.x = fp_one(); gp.y = fp_norm(fp_add(fp_one(), fp_one())); gp.inf = false;
   A = proj_select(live, A, proj_from_affine(gp));       // placeholders keep every lane on well-formed values
   B = proj_select(live, B, proj_from_affine(gp));
   g1_encode(c_sig + 64 * c, g1_to_affine(A));
-  store_g1p(c_h + c, m, B);
-  c_state[c] = elig == 0 ? 0 : degenerate ? 2 : 1;
+  store_g1p(c_h + c, stride, B);
+  c_state[c] = elig[c] == 0 ? 0 : degenerate ? 2 : 1;
+}
+// The key round: *all_pass stays 1 iff every key with eligible tuples and a valid key passed its one check
+// (keys that failed their own checks need none: their tuples are invalid whatever the signatures)
+__global__ void k_rlc2_keys_pass(const uint8_t* key_ok, const uint8_t* state, const uint8_t* isone, uint32_t u, uint8_t* key_pass, int* all_pass) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= u) return;
+  const bool pass = state[k] == 0 || key_ok[k] == 0 || (state[k] == 1 && isone[k] != 0);
+  key_pass[k] = pass ? 1 : 0;
+  if (!pass) atomicAnd(all_pass, 0);
+}
+// the chunks that still need their own check: those of the keys that failed the key round.  need[c], and the count per workgroup
+// (block_cnt[nblocks] = 0) for the ordered compaction (k_rlc2_compact with perm = the identity gives the list of chunk indices)
+__global__ void __launch_bounds__(256) k_rlc2_chunk_need(const uint32_t* chunk_kid, const uint8_t* key_pass, uint32_t m, uint8_t* need, uint32_t* block_cnt) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool nd = c < m && key_pass[chunk_kid[c]] == 0;
+  if (c < m) need[c] = nd ? 1 : 0;
+  const int cnt = __syncthreads_count(nd);
+  if (threadIdx.x == 0) { block_cnt[blockIdx.x] = (uint32_t)cnt; if (blockIdx.x == gridDim.x - 1) block_cnt[gridDim.x] = 0; }
+}
+// results of a chunk round over the listed chunks (position j of the round = chunk list[j], or j without a list)
+__global__ void k_rlc2_chunk_pass(const uint32_t* list, const uint8_t* state, const uint8_t* isone, const uint8_t* flags, uint32_t cnt, uint8_t* chunk_pass) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= cnt) return;
+  const uint32_t c = list ? list[j] : j;
+  chunk_pass[c] = (state[c] == 1 && isone[j] != 0 && flags[j] != 0) ? 1 : 0;
+}
+// ... and then every tuple is decided by its own prechecks
+__global__ void k_rlc2_valid_fast(const uint32_t* perm, const uint32_t* kid, const uint8_t* sig_ok, const uint8_t* key_ok, uint32_t n, uint8_t* valid) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const uint32_t i = perm[s];
+  valid[i] = (sig_ok[s] != 0 && key_ok[kid[i]] != 0) ? 1 : 0;
 }
 __global__ void k_iota_u32(uint32_t* out, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -121,14 +168,13 @@ __global__ void k_iota_u32(uint32_t* out, uint32_t n) {
 // After the chunk round: valid[i] for every tuple that is decided, need[s] = 1 where the exact path must decide
 // (eligible tuple of a failed chunk), block_cnt[b] = number of such positions in workgroup b (block_cnt[nblocks] = 0).
 __global__ void __launch_bounds__(256) k_rlc2_resolve(const uint32_t* perm, const uint32_t* kid, const uint32_t* tuple_chunk, const uint8_t* sig_ok,
-                                                      const uint8_t* key_ok, const uint8_t* c_state, const uint8_t* c_isone, const uint8_t* c_flags,
-                                                      uint32_t n, uint8_t* valid, uint8_t* need, uint32_t* block_cnt) {
+                                                      const uint8_t* key_ok, const uint8_t* chunk_pass, uint32_t n, uint8_t* valid, uint8_t* need, uint32_t* block_cnt) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   bool nd = false;
   if (s < n) {
-    const uint32_t i = perm[s], c = tuple_chunk[s];
+    const uint32_t i = perm[s];
     const bool elig = sig_ok[s] != 0 && key_ok[kid[i]] != 0;
-    const bool pass = c_state[c] == 1 && c_isone[c] != 0 && c_flags[c] != 0;
+    const bool pass = chunk_pass[tuple_chunk[s]] != 0;           // its chunk passed, or its whole key did in the key round
     valid[i] = (elig && pass) ? 1 : 0;
     nd = elig && !pass;
     need[s] = nd ? 1 : 0;

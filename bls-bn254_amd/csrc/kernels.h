@@ -78,11 +78,17 @@ __global__ void k_rlc2_chunk_counts(const uint32_t* hist, uint32_t u, uint32_t G
 __global__ void k_rlc2_mark(const uint32_t* perm, const uint32_t* kid, const uint32_t* hist, const uint32_t* run_end, const uint32_t* chunk_base,
                             uint32_t n, uint32_t G, uint32_t* tuple_chunk, uint32_t* chunk_kid, uint32_t* chunk_start, uint32_t* chunk_len);
 BN_KERNEL k_rlc2_sum(const int32_t* a_ws, const int32_t* b_ws, size_t n, const uint8_t* sig_ok, const uint32_t* chunk_start, const uint32_t* chunk_len,
-                     size_t m, uint8_t* c_sig, int32_t* c_h, uint8_t* c_state);
+                     size_t m, int32_t* sa_ws, int32_t* sb_ws, uint32_t* elig_out);
+__global__ void k_rlc2_key_elig(const uint32_t* chunk_kid, const uint32_t* chunk_elig, uint32_t m, uint32_t* key_elig);
+BN_KERNEL k_rlc2_virtual(const int32_t* sa_ws, const int32_t* sb_ws, size_t stride, const uint32_t* elig, const uint32_t* list, size_t cnt,
+                         uint8_t* c_sig, int32_t* c_h, uint8_t* c_state);
+__global__ void k_rlc2_keys_pass(const uint8_t* key_ok, const uint8_t* state, const uint8_t* isone, uint32_t u, uint8_t* key_pass, int* all_pass);
+__global__ void __launch_bounds__(256) k_rlc2_chunk_need(const uint32_t* chunk_kid, const uint8_t* key_pass, uint32_t m, uint8_t* need, uint32_t* block_cnt);
+__global__ void k_rlc2_chunk_pass(const uint32_t* list, const uint8_t* state, const uint8_t* isone, const uint8_t* flags, uint32_t cnt, uint8_t* chunk_pass);
+__global__ void k_rlc2_valid_fast(const uint32_t* perm, const uint32_t* kid, const uint8_t* sig_ok, const uint8_t* key_ok, uint32_t n, uint8_t* valid);
 __global__ void k_iota_u32(uint32_t* out, uint32_t n);
 __global__ void __launch_bounds__(256) k_rlc2_resolve(const uint32_t* perm, const uint32_t* kid, const uint32_t* tuple_chunk, const uint8_t* sig_ok,
-                                                      const uint8_t* key_ok, const uint8_t* c_state, const uint8_t* c_isone, const uint8_t* c_flags,
-                                                      uint32_t n, uint8_t* valid, uint8_t* need, uint32_t* block_cnt);
+                                                      const uint8_t* key_ok, const uint8_t* chunk_pass, uint32_t n, uint8_t* valid, uint8_t* need, uint32_t* block_cnt);
 __global__ void __launch_bounds__(256) k_rlc2_compact(const uint8_t* need, const uint32_t* perm, uint32_t n, const uint32_t* block_base, uint32_t* list);
 BN_KERNEL k_g1_seg_sum(const int32_t* in_ws, size_t in_stride, const uint32_t* perm, const uint32_t* chunk_start, const uint32_t* chunk_len, size_t m,
                        int32_t* out_ws, size_t out_stride);

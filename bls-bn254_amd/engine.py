@@ -274,9 +274,14 @@ class Engine:
 
     def rlc_stats(self):
         """dict: tuples verified through chunks, chunks checked, tuples re-verified exactly, tuples of distinct-key batches"""
-        o = (ctypes.c_uint64 * 4)()
+        o = (ctypes.c_uint64 * 6)()
         self._chk(self._lib.blsbn254_rlc_stats(self._ctx, o))
-        return {"chunked_tuples": int(o[0]), "chunks": int(o[1]), "fallback_tuples": int(o[2]), "distinct_key_tuples": int(o[3])}
+        return {"chunked_tuples": int(o[0]), "chunks": int(o[1]), "fallback_tuples": int(o[2]), "distinct_key_tuples": int(o[3]),
+                "key_rounds": int(o[4]), "key_rounds_passed": int(o[5])}
+
+    def set_rlc_key_round(self, on):
+        """RLC: check every key's whole run as one virtual tuple first (default on)"""
+        self._chk(self._lib.blsbn254_set_rlc_key_round(self._ctx, ctypes.c_int(1 if on else 0)))
 
     def aggregate_verify(self, pks, msgs, agg_sig, dst=DEFAULT_DST):
         n = len(msgs)

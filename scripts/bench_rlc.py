@@ -35,6 +35,7 @@ for name, inv in (("1/64 invalid (bench workload: invalid tuples on 16 keys)", 6
             e.set_rlc_group(g)
         fn = (lambda: e.verify_batch_rlc_dev(*args)) if g is not None else (lambda: e.verify_batch_dev(*args))
         t_bm.zero_()
+        e.set_rlc_key_round(True)                   # fresh back-off state for every measurement
         fn(); e.synchronize()
         assert bytes(t_bm.cpu().numpy()) == want, label
         s0 = e.rlc_stats()
@@ -52,6 +53,7 @@ for name, inv in (("1/64 invalid (bench workload: invalid tuples on 16 keys)", 6
         if g is not None:
             res[label]["chunks_per_step"] = (s1["chunks"] - s0["chunks"]) // reps
             res[label]["fallback_tuples_per_step"] = (s1["fallback_tuples"] - s0["fallback_tuples"]) // reps
+            res[label]["key_rounds_that_decided"] = "%d of %d" % (s1["key_rounds_passed"] - s0["key_rounds_passed"], s1["key_rounds"] - s0["key_rounds"])
     # Throughput with several batches in flight: K contexts (own stream + workspace each) driven by K host threads.  A single
     # RLC call is latency-bound in its chunk round (a quarter of the SIMDs busy); with two or three calls in flight the
     # rounds of one overlap the hashing / weighting of another.  The exact path fills the chip by itself (shown for contrast).
@@ -60,6 +62,7 @@ for name, inv in (("1/64 invalid (bench workload: invalid tuples on 16 keys)", 6
         for label, rlc in (("exact", False), ("rlc_auto", True)):
             for K in pipeline:
                 engs = [e] + [M.Engine(0) for _ in range(K - 1)]
+                e.set_rlc_key_round(True)
                 bms = [torch.zeros((n + 7) // 8, dtype=torch.uint8, device=dev) for _ in range(K)]
                 torch.cuda.synchronize()
                 reps = 6

@@ -506,7 +506,7 @@ def test_verify_batch_rlc_repeated_keys_group_sizes(eng, oracle, M, group):
     finally:
         eng.set_rlc_group(0)                      # back to automatic
     assert after["chunked_tuples"] - before["chunked_tuples"] == n
-    assert (n + group - 1) // group <= after["chunks"] - before["chunks"] <= n // group + 9      # at most one partial chunk per distinct key
+    assert 0 < after["chunks"] - before["chunks"] <= n // group + 9      # the chunks of the keys that failed the key round; at most one partial chunk per key
     assert 0 < after["fallback_tuples"] - before["fallback_tuples"] <= n
 
 
@@ -514,12 +514,34 @@ def test_verify_batch_rlc_all_valid_has_no_fallback(eng, oracle, M):
     dst = M.DEFAULT_DST
     n = 2048
     pks, msgs, sigs, exp = synth.make_batch_gpu(eng, oracle, n, dst, pool=16, invalid_every=0, spot=20)
+    eng.set_rlc_key_round(True)                               # (also clears the back-off earlier failing batches left behind)
     before = eng.rlc_stats()
     assert eng.verify_batch_rlc(pks, msgs, sigs, dst) == synth.bitmap_of(exp) == b"\xff" * (n // 8)
     after = eng.rlc_stats()
     assert after["chunked_tuples"] - before["chunked_tuples"] == n
-    assert after["chunks"] - before["chunks"] == n // 16
-    assert after["fallback_tuples"] == before["fallback_tuples"]
+    # the key round (16 checks, one per key) decides an all-valid batch: no chunk is looked at
+    assert (after["key_rounds"] - before["key_rounds"], after["key_rounds_passed"] - before["key_rounds_passed"]) == (1, 1)
+    assert after["chunks"] == before["chunks"] and after["fallback_tuples"] == before["fallback_tuples"]
+    eng.set_rlc_key_round(False)                              # without it: every chunk is checked, none fails
+    try:
+        assert eng.verify_batch_rlc(pks, msgs, sigs, dst) == b"\xff" * (n // 8)
+    finally:
+        eng.set_rlc_key_round(True)
+    last = eng.rlc_stats()
+    assert last["chunks"] - after["chunks"] == n // 16 and last["fallback_tuples"] == after["fallback_tuples"] and last["key_rounds"] == after["key_rounds"]
+    # one bad signature: its key fails the key round, its chunk fails the chunk round, 16 tuples are re-verified
+    bad = bytearray(sigs); bad[64 * 100:64 * 101] = sigs[64 * 101:64 * 102]
+    want = bytearray(b"\xff" * (n // 8)); want[100 // 8] &= ~(1 << (100 % 8)) & 0xff
+    assert eng.verify_batch_rlc(pks, msgs, bytes(bad), dst) == bytes(want)
+    end = eng.rlc_stats()
+    assert (end["key_rounds"] - last["key_rounds"], end["key_rounds_passed"] - last["key_rounds_passed"]) == (1, 0)
+    assert end["chunks"] - last["chunks"] == n // 16 // 16 and end["fallback_tuples"] - last["fallback_tuples"] == 16    # only the 8 chunks of that key
+    # back-off: after that failure the next two batches skip the key round (all chunks are checked), the third runs it again
+    for expect_round in (0, 0, 1):
+        s0 = eng.rlc_stats()
+        assert eng.verify_batch_rlc(pks, msgs, sigs, dst) == b"\xff" * (n // 8)
+        s1 = eng.rlc_stats()
+        assert s1["key_rounds"] - s0["key_rounds"] == expect_round and s1["chunks"] - s0["chunks"] == (0 if expect_round else n // 16)
 
 
 def test_verify_batch_rlc_dev_full_size(eng, oracle, M):
