@@ -544,6 +544,28 @@ def test_verify_batch_rlc_all_valid_has_no_fallback(eng, oracle, M):
         assert s1["key_rounds"] - s0["key_rounds"] == expect_round and s1["chunks"] - s0["chunks"] == (0 if expect_round else n // 16)
 
 
+@pytest.mark.parametrize("n,pool", [(3000, 2), (40000, 3)])
+def test_verify_batch_rlc_key_round_over_long_runs(eng, oracle, M, n, pool):
+    """keys with hundreds / thousands of chunks each: the key round sums them level by level (key_sums); a valid batch is
+    decided by `pool` checks, one wrong signature sends exactly its key's chunks to the chunk round"""
+    dst = M.DEFAULT_DST
+    pks, msgs, sigs, exp = synth.make_batch_gpu(eng, oracle, n, dst, pool=pool, invalid_every=0, spot=10)
+    full = synth.bitmap_of(exp)
+    eng.set_rlc_key_round(True)
+    s0 = eng.rlc_stats()
+    assert eng.verify_batch_rlc(pks, msgs, sigs, dst) == full
+    s1 = eng.rlc_stats()
+    assert s1["key_rounds_passed"] - s0["key_rounds_passed"] == 1 and s1["chunks"] == s0["chunks"]
+    j = n // 2 + 1
+    bad = bytearray(sigs); bad[64 * j:64 * j + 64] = sigs[64 * (j - 1):64 * j]
+    want = bytearray(full); want[j // 8] &= ~(1 << (j % 8)) & 0xff
+    assert eng.verify_batch_rlc(pks, msgs, bytes(bad), dst) == bytes(want)
+    s2 = eng.rlc_stats()
+    run = len(range(j % pool, n, pool))                        # tuples of the bad tuple's key
+    assert s2["chunks"] - s1["chunks"] == (run + 15) // 16 and s2["fallback_tuples"] - s1["fallback_tuples"] in (15, 16)
+    eng.set_rlc_key_round(True)
+
+
 def test_verify_batch_rlc_dev_full_size(eng, oracle, M):
     """BASELINE configs[1] size through the device entry point: same bitmap as verify_batch_dev and as the closed form."""
     import torch
