@@ -69,3 +69,12 @@ def test_rocprof_summary_agrees_with_the_bench_line():
     if b["roofline"].get("traffic") is not None:
         t = json.load(open(os.path.join(ROOT, "profiles", tag + "_traffic.json")))
         assert t["kernels"][b["roofline"]["kernel"]]["hbm_bytes_per_launch"] == b["roofline"]["traffic"]
+
+
+def test_scripts_compile():
+    """every helper script under scripts/ (GPU benchmarks, profiling summaries, differential runs) at least parses"""
+    import py_compile
+    d = os.path.join(ROOT, "scripts")
+    for f in sorted(os.listdir(d)):
+        if f.endswith(".py"):
+            py_compile.compile(os.path.join(d, f), doraise=True)
