@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-paths", action="store_true",
                     help="skip the untimed exact_path / rlc_path legs (profiling runs: keeps rocprofv3's per-kernel averages to the timed path)")
+    ap.add_argument("--key-pool", dest="pool", type=int, default=1024,
+                    help="distinct public keys in the batch (SURVEY.md 8d: 1024); 0 = every tuple has its own key (the all-distinct case)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N>1 on one GPU)")
     ap.add_argument("--all-on-device0", action="store_true", help="rehearsal: every rank uses cuda:0")
     args = ap.parse_args()
@@ -64,6 +66,9 @@ def spawn_ranks(args):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ)
+    # The host driver of this pool only supports dmabuf IPC: with the legacy IPC mode RCCL's intra-node transport setup
+    # (and any CUDA-tensor sharing across processes) fails with `hipIpcGetMemHandle: invalid argument`.  The image exports
+    # this already; it is pinned here so that the ranks get it whatever shell started the bench.
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -104,7 +109,9 @@ def run_rank(args):
 
     # synthetic batch: n UNIQUE tuples per rank (global indices lo..lo+n), key pool of 1024, signed by the
     # engine's own GPU signing kernels and spot-checked at 1000 random indices against the CPU oracle; 1/64 corrupted
-    pks, msgs, sigs, exp = synth.make_batch_gpu(eng, O, n, dst, pool=1024, invalid_every=INVALID_EVERY, spot=1000, base=lo)
+    pool = args.pool if args.pool > 0 else n
+    t_gen = time.perf_counter()
+    pks, msgs, sigs, exp = synth.make_batch_gpu(eng, O, n, dst, pool=pool, invalid_every=INVALID_EVERY, spot=1000, base=lo)
     data, off = M.engine.pack_messages(msgs)
     t_pk = torch.frombuffer(bytearray(pks), dtype=torch.uint8).to(dev)
     t_sg = torch.frombuffer(bytearray(sigs), dtype=torch.uint8).to(dev)
@@ -113,12 +120,21 @@ def run_rank(args):
     t_bm = torch.zeros((n + 7) // 8, dtype=torch.uint8, device=dev)
     del pks, sigs, data, msgs
     torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    if rank == 0:
+        print("bench: rank 0 generated and staged %d tuples in %.1f s (GPU signing + oracle spot checks; outside the timed region)" % (n, t_gen),
+              file=sys.stderr, flush=True)
+    ar_ms = []                                # per step: the bitmap exchange alone (N > 1)
 
     def step():
         eng.verify_batch_dev(t_pk.data_ptr(), t_ms.data_ptr(), t_off.data_ptr(), t_sg.data_ptr(), n, t_bm.data_ptr(), dst)
         eng.synchronize()                     # the engine runs on its own stream
         if world > 1:
-            return sharded.allreduce_bitmap(t_bm, lo, n, n_total, dist, torch)
+            ta = time.perf_counter()
+            w = sharded.allreduce_bitmap(t_bm, lo, n, n_total, dist, torch)
+            torch.cuda.synchronize()
+            ar_ms.append((time.perf_counter() - ta) * 1e3)
+            return w
         return None
 
     def barrier():
@@ -140,8 +156,10 @@ def run_rank(args):
     barrier()
     t0 = time.perf_counter()
     words = None
+    del ar_ms[:]
     for _ in range(args.steps):
         words = step()
+    dt_own = time.perf_counter() - t0         # this rank's own K steps, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
     prof = eng.profile_read()
@@ -150,6 +168,17 @@ def run_rank(args):
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # per-rank spread (a straggler would show here) and the cost of the exchange itself
+        ar_mean = sum(ar_ms) / max(len(ar_ms), 1)
+        lo_t = torch.tensor([dt_own, ar_mean, t_gen], dtype=torch.float64, device=dev)
+        hi_t = lo_t.clone()
+        dist.all_reduce(lo_t, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_t, op=dist.ReduceOp.MAX)
+        rank_spread = {"ms_per_step_min": round(float(lo_t[0]) / args.steps * 1e3, 3), "ms_per_step_max": round(float(hi_t[0]) / args.steps * 1e3, 3),
+                       "allreduce_ms_min": round(float(lo_t[1]), 3), "allreduce_ms_max": round(float(hi_t[1]), 3),
+                       "datagen_s_max": round(float(hi_t[2]), 1),
+                       "note": "per rank: its own K steps before the closing barrier (verify + bitmap exchange), and the exchange alone "
+                               "(all_reduce of %d int32 words + synchronize); datagen is outside the timed region" % ((n_total + 31) // 32)}
         # every rank holds the same full bitmap: check it against the closed-form expectation over all global indices
         full = sharded.words_to_bitmap_bytes(words.cpu().numpy(), n_total)
         if full != synth.bitmap_of(synth.expected_bits(n_total, INVALID_EVERY)):
@@ -198,9 +227,9 @@ def run_rank(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
             "config": {"workload": "%d batched single-sig BLS verifies per GPU (%s), unique 32-byte messages, "
-                                   "1024-key pool, 1/64 invalid tuples; key de-duplication + hash-to-G1 + per-key G2 checks and line tables "
-                                   "+ 2-pair Miller loop + final exp" % (n, wl),
-                       "tuples_per_gpu": n, "tuples_total": n_total,
+                                   "%s, 1/64 invalid tuples; key de-duplication + hash-to-G1 + per-key G2 checks and line tables "
+                                   "+ 2-pair Miller loop + final exp" % (n, wl, ("%d-key pool" % pool) if args.pool > 0 else "every tuple its own public key"),
+                       "tuples_per_gpu": n, "tuples_total": n_total, "key_pool": pool, "datagen_s": round(t_gen, 1),
                        "path": "prepared-keys (distinct public keys validated and turned into line tables once per batch, inside the timed step)"
                                if prepared else "exact per-tuple"},
             "roofline": {"bound": "valu", "kernel": "k_" + dom, "achieved": round(achieved, 4), "peak": round(peak, 3),
@@ -224,6 +253,8 @@ def run_rank(args):
             "algorithmic_fp_mul_per_verify": {"miller_variable_pair": core[0], "miller_fixed_pair_lines": core[1], "final_exp": core[2],
                                               "miller_shared_squarings": core[4], "dominant_kernel": alg_fp_mul},
         }
+        if world > 1:
+            out["ranks"] = rank_spread
         if world == 1 and prepared and not args.no_side_paths:
             # the same batch through the exact per-tuple path (what a batch of all-distinct keys takes), reported beside the
             # headline so that the number does not hinge on the workload's key pool; outside the timed region above

@@ -70,6 +70,10 @@ BN_INL GlvSplit glv_split(const uint32_t* k) {
   s.neg1 = (k1[7] >> 31) != 0; s.neg2 = (k2[7] >> 31) != 0;
   if (s.neg1) neg_256(k1);
   if (s.neg2) neg_256(k2);
+#ifdef BN_CHECK
+  // hostsim: the halves must fit the 128 bits the window kernels read (analytic bound asserted in tools/gen_constants.py)
+  if (k1[4] | k1[5] | k1[6] | k1[7] | k2[4] | k2[5] | k2[6] | k2[7]) check_fail("glv_split half exceeds 128 bits", 0);
+#endif
   BN_UNROLL for (int i = 0; i < 4; ++i) { s.k1[i] = k1[i]; s.k2[i] = k2[i]; }
   return s;
 }

@@ -36,7 +36,8 @@ def allreduce_bitmap(local_bm, lo, m, n, dist, torch, group=None):
     """local_bm: uint8 tensor, LSB-first bitmap of this rank's m tuples (global indices lo..lo+m).
     Returns the full-batch bitmap as an int32 word tensor, identical on every rank."""
     nwords = (n + 31) // 32
-    if lo % 32 == 0 and m % 32 == 0 and local_bm.numel() * 8 >= m:
+    if (lo % 32 == 0 and m % 32 == 0 and local_bm.numel() * 8 >= m and local_bm.is_contiguous()
+            and local_bm.storage_offset() % 4 == 0):
         # word-aligned shard (every power-of-two batch): the local bytes ARE the shard's words
         words = torch.zeros(nwords, dtype=torch.int32, device=local_bm.device)
         if m:

@@ -346,6 +346,10 @@ def glv_constants():
     n1, n2 = b2 * (1 if det > 0 else -1), -b1 * (1 if det > 0 else -1)
     c = {"lam": lam, "beta": beta, "a1": a1, "b1": b1, "a2": a2, "b2": b2,
          "g1": (abs(n1) << 256) // RR, "g2": (abs(n2) << 256) // RR, "c1_neg": n1 < 0, "c2_neg": n2 < 0}
+    # Analytic bound on the halves (the device code hard-codes 128-bit magnitudes: glv.h, k_msm_window): with exact rounding
+    # |k1| <= (|a1| + |a2|) / 2, |k2| <= (|b1| + |b2|) / 2; each of the two truncated quotients is off by less than 2 (one
+    # for the floor of g = 2^256 n / r, one for the floor of the product), i.e. less than 1.5 further basis vectors each.
+    assert 2 * (abs(a1) + abs(a2)) < 1 << 128 and 2 * (abs(b1) + abs(b2)) < 1 << 128, "GLV halves may exceed 128 bits"
     # the truncated quotients are off by at most one: the halves must still fit 128 bits with room to spare
     rnd = random.Random(7)
     worst = 0

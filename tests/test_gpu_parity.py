@@ -589,6 +589,65 @@ def test_verify_batch_rlc_dev_full_size(eng, oracle, M):
     assert bytes(t_b.cpu().numpy()) == want
 
 
+def test_verify_batch_dev_1m_per_gpu_shape(eng, oracle, M):
+    """BASELINE configs[3]'s per-GPU shape: 1 048 576 unique GPU-signed tuples (1024-key pool, 1/64 invalid) through the device
+    entry point, on the prepared-key path and with BLSBN254_AUTO_PREPARE=0 (the exact per-tuple path): both bitmaps equal the
+    closed form.  (The 8-GPU run itself is the driver's; this is what every rank of it executes.)"""
+    import torch
+    dst = M.DEFAULT_DST
+    n = 1 << 20
+    pks, msgs, sigs, exp = synth.make_batch_gpu(eng, oracle, n, dst, pool=1024, invalid_every=64, spot=64)
+    want = synth.bitmap_of(exp)
+    assert want == synth.bitmap_of(synth.expected_bits(n, 64))
+    data, off = M.engine.pack_messages(msgs)
+    dev = torch.device("cuda", 0)
+    t_pk = torch.frombuffer(bytearray(pks), dtype=torch.uint8).to(dev)
+    t_sg = torch.frombuffer(bytearray(sigs), dtype=torch.uint8).to(dev)
+    t_ms = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+    t_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    del pks, sigs, data, msgs
+    t_bm = torch.zeros((n + 7) // 8, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    p0, e0 = eng.path_stats()
+    eng.verify_batch_dev(t_pk.data_ptr(), t_ms.data_ptr(), t_off.data_ptr(), t_sg.data_ptr(), n, t_bm.data_ptr(), dst)
+    eng.synchronize()
+    assert bytes(t_bm.cpu().numpy()) == want
+    assert eng.path_stats() == (p0 + 1, e0)
+    t_bm.zero_()
+    eng.set_auto_prepare(False)
+    try:
+        eng.verify_batch_dev(t_pk.data_ptr(), t_ms.data_ptr(), t_off.data_ptr(), t_sg.data_ptr(), n, t_bm.data_ptr(), dst)
+        eng.synchronize()
+    finally:
+        eng.set_auto_prepare(True)
+    assert bytes(t_bm.cpu().numpy()) == want
+    assert eng.path_stats() == (p0 + 1, e0 + 1)
+
+
+def test_aggregate_verify_all_distinct_after_small_verify(oracle, M):
+    """Regression: verify_batch of 64 tuples sizes the key-id buffers for 64 entries; an aggregate_verify over 136
+    DISTINCT keys on the same context then appends the signature's key (-G2gen) as entry u = n of kd_keys -- one past 4 n bytes."""
+    dst = M.DEFAULT_DST
+    e = M.Engine(0)
+    try:
+        pks, msgs, sigs, exp = synth.make_batch(oracle, 64, dst, invalid_every=5, uniq=16)
+        assert e.verify_batch(pks, msgs, sigs, dst) == synth.bitmap_of(exp)
+        n = 136
+        sks = [synth.sk_of(1000 + k) for k in range(n)]
+        skb = b"".join(x.to_bytes(32, "big") for x in sks)
+        pk = e.sk_to_pk_batch(skb, n)
+        assert pk[:128] == oracle.sk_to_pk(sks[0]) and pk[-128:] == oracle.sk_to_pk(sks[-1])
+        ms = [synth.msg_of(7000 + i) for i in range(n)]
+        sg = e.sign_batch(skb, ms, dst)
+        agg = e.aggregate_sigs(sg, n)
+        assert agg == oracle.aggregate_sigs(sg, n)
+        assert e.aggregate_verify(pk, ms, agg, dst) is True
+        ms[n - 1] = b"tampered"
+        assert e.aggregate_verify(pk, ms, agg, dst) is False
+    finally:
+        e.close()
+
+
 def test_verify_batch_rlc_edge_cases(eng, oracle, pyref, M, monkeypatch):
     """Repeated-key RLC path on awkward batches: a key none of whose tuples is eligible (every signature off the curve), a key
     outside the subgroup carrying many tuples, the distinct / repeated switch-over (n = 2 u), identity signatures, and a batch
@@ -706,7 +765,11 @@ def test_chunked_prepared_paths(oracle, M, monkeypatch):
     try:
         p0, e0 = e.path_stats()
         assert e.verify_batch(pks, msgs, sigs, dst) == want
-        assert e.path_stats() == (p0 + 3, e0)                      # every chunk on the prepared path (the 900-tuple tail as a small chunk: one wave per tuple)
+        # the two full chunks take the prepared path in either mode; the 900-tuple tail takes it as a small chunk (one wave per
+        # tuple) only while the wave-per-tuple kernels are on -- with BLSBN254_WIDE_FE=0 (a documented production knob) a chunk
+        # below 1024 tuples goes down the exact per-tuple path
+        wide = os.environ.get("BLSBN254_WIDE_FE", "1") != "0" and int(os.environ.get("BLSBN254_WIDE_FE_MAX", "4096")) >= 900
+        assert e.path_stats() == ((p0 + 3, e0) if wide else (p0 + 2, e0 + 1))
         keys = sorted(set(pks[128 * i:128 * i + 128] for i in range(n)))
         index = {k: j for j, k in enumerate(keys)}
         prep = e.g2_prepare_batch(b"".join(keys), len(keys))

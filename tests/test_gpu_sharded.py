@@ -88,13 +88,16 @@ def _agg_worker(rank, world, port, n, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,rlc", [(37, False), (256, False), (256, True)])
+@pytest.mark.parametrize("n,rlc", [(37, False), (256, False), (256, True), (2 * 65536, False)])
 def test_world2_verify_batch_sharded_with_engine(tmp_path, oracle, n, rlc):
+    """n = 2 x 65536: every rank runs a full round of waves on the lane-per-tuple kernels (the shape of a real rank), not the
+    wave-per-tuple small-call path; the expectation there is the closed form (the oracle would need minutes)."""
     import torch.multiprocessing as mp
     mp.spawn(_verify_worker, args=(2, _free_port(), n, str(tmp_path), rlc), nprocs=2, join=True)
     pks, msgs, sigs, exp = synth.make_batch(oracle, n, b"TEST_DST", invalid_every=3, uniq=12)
-    want = oracle.verify_batch(pks, msgs, sigs, b"TEST_DST", nthreads=4)
-    assert want == synth.bitmap_of(exp)
+    want = synth.bitmap_of(exp)
+    if n <= 4096:
+        assert oracle.verify_batch(pks, msgs, sigs, b"TEST_DST", nthreads=4) == want
     for r in range(2):
         assert np.load(tmp_path / ("v%d.npy" % r)).tobytes() == want
 
