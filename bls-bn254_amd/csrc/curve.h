@@ -176,6 +176,25 @@ template <class F> BN_FUNC Proj<F> proj_mul_256(const Proj<F>& p, const uint64_t
   }
   return acc;
 }
+// k * P for a per-lane 256-bit scalar with 4-bit fixed windows: 252 doublings + 63 additions + 14 table additions instead of
+// 256 + 256 (Mul<Scalar>, g1.rs:518-534 / g2.rs:866-886: same point as the reference's double-and-add).  The table index is
+// per lane (the table lives in scratch); the control flow is uniform, and adding the table's identity entry is just another
+// complete addition.
+template <class F> BN_FUNC Proj<F> proj_mul_win4(const Proj<F>& p, const uint64_t* k) {
+  BN_CTX;
+  Proj<F> tab[16];
+  tab[0] = proj_identity<F>();
+  tab[1] = p;
+  for (int i = 2; i < 16; ++i) tab[i] = proj_add(tab[i - 1], p);
+  Proj<F> acc = tab[(int)(k[3] >> 60)];
+  for (int w = 62; w >= 0; --w) {
+    const int d = (int)((k[w >> 4] >> ((w & 15) * 4)) & 15);
+    const Proj<F> t = tab[d];
+    acc = proj_dbl(proj_dbl(proj_dbl(proj_dbl(acc))));
+    acc = proj_add(acc, t);
+  }
+  return acc;
+}
 template <class F> BN_INL bool proj_eq(const Proj<F>& a, const Proj<F>& b) {
   bool ai = f_is_zero(a.z), bi = f_is_zero(b.z);
   bool e = f_is_zero(f_sub(f_mul(a.x, b.z), f_mul(b.x, a.z))) & f_is_zero(f_sub(f_mul(a.y, b.z), f_mul(b.y, a.z)));

@@ -67,6 +67,9 @@ void blsbn254_ctx_destroy(blsbn254_ctx* c) {
   for (DevBuf* b : bufs) b->release();
   for (DevBuf& b : c->fe) b.release();
   c->fe_slots.release(); c->fe_wide_one.release();
+  for (DevBuf& b : c->gs_ws) b.release();
+  for (DevBuf& b : c->gs_ok) b.release();
+  c->gs_start.release(); c->gs_len.release(); c->gs_pk.release();
   { DevBuf* tb[] = {&c->th_x, &c->th_num, &c->th_den, &c->th_glv, &c->th_part, &c->th_part2, &c->q_ws}; for (DevBuf* b : tb) b->release(); }
   { DevBuf* rb[] = {&c->rlc_a2, &c->rlc_a, &c->rlc_b, &c->rlc_elig, &c->rlc_f2, &c->rlc_bytes, &c->rlc_neg, &c->rlc_ok, &c->rlc_idx, &c->rlc_cpk, &c->rlc_csig, &c->rlc_ch, &c->rlc_csub, &c->rlc_cbm};
     for (DevBuf* b : rb) b->release(); }

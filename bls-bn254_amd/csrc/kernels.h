@@ -59,6 +59,12 @@ BN_KERNEL k_g1_to_bytes(const int32_t* ws, size_t stride, uint8_t* out);
 BN_KERNEL k_sign(const uint8_t* sks, const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len,
                  uint8_t* sigs, uint8_t* status);
 BN_KERNEL k_sk_to_pk(const uint8_t* sks, size_t n, uint8_t* pks, uint8_t* status);
+BN_KERNEL k_g1_mul(const uint8_t* g1, const uint8_t* scalars, size_t n, uint8_t* out, uint8_t* status);
+BN_KERNEL k_g2_mul(const uint8_t* g2, const uint8_t* scalars, size_t n, uint8_t* out, uint8_t* status);
+BN_KERNEL k_g2_load(const uint8_t* g2, size_t n, int32_t* ws, uint8_t* ok);
+BN_KERNEL k_g2_seg_sum(const int32_t* in_ws, size_t in_stride, const uint8_t* ok_in, const uint32_t* chunk_start, const uint32_t* chunk_len, size_t m,
+                       int32_t* out_ws, size_t out_stride, uint8_t* ok_out);
+BN_KERNEL k_g2p_to_bytes(const int32_t* ws, size_t stride, const uint8_t* ok, size_t m, uint8_t* out, int poison);
 BN_KERNEL k_keygen(const uint8_t* ikm, size_t ikm_len, size_t n, const uint8_t* key_info, size_t key_info_len,
                    uint8_t* sks, uint8_t* status);
 BN_KERNEL k_hash_to_scalar(const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, uint32_t dst_len, uint8_t* out);

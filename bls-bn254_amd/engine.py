@@ -328,6 +328,50 @@ class Engine:
         self._chk(self._lib.blsbn254_aggregate_sigs(self._ctx, pa, ctypes.c_size_t(n), po))
         return o.tobytes()
 
+    def aggregate_pks(self, pks, n):
+        """impl Sum for G2Projective (g2.rs:579-583): the sum of n public keys, 128 bytes."""
+        a, pa = _inbuf(pks, 128 * n); o, po = _outbuf(128)
+        self._chk(self._lib.blsbn254_aggregate_pks(self._ctx, pa, ctypes.c_size_t(n), po))
+        return o[:128].tobytes()
+
+    def fast_aggregate_verify(self, pks, n, msg, sig, dst=DEFAULT_DST):
+        """One message signed by n keys: e(sig, -G2gen) * e(H(msg), sum pk_i) == 1."""
+        a, pa = _inbuf(pks, 128 * n); m, pm = _inbuf(msg); s, ps = _inbuf(sig, 64); d, pd = _inbuf(dst)
+        valid = ctypes.c_int(0)
+        self._chk(self._lib.blsbn254_fast_aggregate_verify(self._ctx, pa, ctypes.c_size_t(n), pm, ctypes.c_size_t(len(msg)), ps, pd,
+                                                           ctypes.c_size_t(len(dst)), ctypes.byref(valid)))
+        return bool(valid.value)
+
+    def fast_aggregate_verify_batch(self, key_sets, msgs, sigs, dst=DEFAULT_DST):
+        """key_sets: list of byte strings (each a multiple of 128 bytes: the keys of one group); msgs: one message per group;
+        sigs: 64 bytes per group.  Returns the LSB-first bitmap over the groups."""
+        g = len(msgs)
+        if len(key_sets) != g:
+            raise ValueError("one key set per message")
+        koff = np.zeros(g + 1, dtype=np.uint64)
+        for i, ks in enumerate(key_sets):
+            if len(ks) % 128:
+                raise ValueError("a key set must be a multiple of 128 bytes")
+            koff[i + 1] = koff[i] + len(ks) // 128
+        allk = b"".join(key_sets)
+        data, off = pack_messages(msgs)
+        a, pa = _inbuf(allk); m, pm = _inbuf(data); s, ps = _inbuf(sigs, 64 * g); d, pd = _inbuf(dst); o, po = _outbuf((g + 7) // 8)
+        self._chk(self._lib.blsbn254_fast_aggregate_verify_batch(self._ctx, pa, koff.ctypes.data_as(_u64p), pm, off.ctypes.data_as(_u64p), ps,
+                                                                 ctypes.c_size_t(g), pd, ctypes.c_size_t(len(dst)), po))
+        return o[:(g + 7) // 8].tobytes()
+
+    def g1_mul_batch(self, g1, scalars, n):
+        """Mul<Scalar> for G1Projective (g1.rs:518-534), element-wise: [k_i] P_i."""
+        a, pa = _inbuf(g1, 64 * n); k, pk = _inbuf(scalars, 32 * n); o, po = _outbuf(64 * n)
+        self._chk(self._lib.blsbn254_g1_mul_batch(self._ctx, pa, pk, ctypes.c_size_t(n), po))
+        return o[:64 * n].tobytes()
+
+    def g2_mul_batch(self, g2, scalars, n):
+        """Mul<Scalar> for G2Projective (g2.rs:866-886), element-wise: [k_i] Q_i."""
+        a, pa = _inbuf(g2, 128 * n); k, pk = _inbuf(scalars, 32 * n); o, po = _outbuf(128 * n)
+        self._chk(self._lib.blsbn254_g2_mul_batch(self._ctx, pa, pk, ctypes.c_size_t(n), po))
+        return o[:128 * n].tobytes()
+
     def threshold_combine(self, ids, partial_sigs, t):
         a, pa = _inbuf(ids, 32 * t); s, ps = _inbuf(partial_sigs, 64 * t); o, po = _outbuf(64)
         self._chk(self._lib.blsbn254_threshold_combine(self._ctx, pa, ps, ctypes.c_size_t(t), po))

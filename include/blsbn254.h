@@ -199,6 +199,34 @@ int blsbn254_set_rlc_key_round(blsbn254_ctx* ctx, int on);
 int blsbn254_rlc_stats(blsbn254_ctx* ctx, uint64_t out[6]);
 /* impl Sum for G1Projective, g1.rs:561-565 */
 int blsbn254_aggregate_sigs(blsbn254_ctx* ctx, const uint8_t* sigs, size_t n, uint8_t out[64]);
+/* impl Sum for G2Projective, g2.rs:579-583: out = pk_0 + ... + pk_(n-1) (uncompressed; the identity encoding for n == 0).
+ * Every point must decode and lie on the curve (else BLSBN254_ERR_G2); subgroup membership is not required of the terms
+ * (the reference's Sum adds whatever G2Projective values it is given). */
+int blsbn254_aggregate_pks(blsbn254_ctx* ctx, const uint8_t* pks /* n*128 */, size_t n, uint8_t out[128]);
+/* IETF FastAggregateVerify, min-sig variant (build-defined composition, SURVEY.md 1: the reference has no BLS layer): ONE message
+ * signed by n keys, e(sig, -G2gen) * e(H(msg), pk_0 + ... + pk_(n-1)) == 1 -- the sum by Sum for G2Projective (g2.rs:579-583),
+ * then the CoreVerify of blsbn254_verify_batch on it (G1Projective::hash g1.rs:910-919, pairing pairings.rs:760-802), including
+ * its KeyValidate on the SUM (not the identity, in the r-torsion).  As in the IETF procedure the individual keys are only
+ * required to be curve points -- proof of possession (blsbn254_pop_verify_batch) is the caller's precondition; a key that
+ * does not decode or is off the curve makes the result invalid, n == 0 likewise.  *valid = 0 / 1. */
+int blsbn254_fast_aggregate_verify(blsbn254_ctx* ctx, const uint8_t* pks /* n*128 */, size_t n, const uint8_t* msg, size_t msg_len,
+                                   const uint8_t sig[64], const uint8_t* dst, size_t dst_len, int* valid);
+/* The same for n_groups independent (key set, message, signature) groups in one call -- the validator workload (thousands of
+ * aggregates, each signed by hundreds of keys): group g owns the keys pks[128 * key_off[g] .. 128 * key_off[g + 1]) (key_off:
+ * n_groups + 1 non-decreasing element offsets, host array), the message msgs[off[g] .. off[g + 1]) and sigs[64 g ..].  The
+ * key sums run as segmented sums on the device (one lane per 16-point chunk, level by level), the n_groups sums then go
+ * through the verify_batch pipeline.  Bit g of valid_bitmap (LSB-first) = group g verifies; a group with an undecodable /
+ * off-curve key or with no key at all is invalid, never an error. */
+int blsbn254_fast_aggregate_verify_batch(blsbn254_ctx* ctx, const uint8_t* pks, const uint64_t* key_off /* n_groups+1 */,
+                                         const uint8_t* msgs, const uint64_t* off /* n_groups+1 */, const uint8_t* sigs /* n_groups*64 */,
+                                         size_t n_groups, const uint8_t* dst, size_t dst_len, uint8_t* valid_bitmap /* ceil(n_groups/8) */);
+/* Mul<Scalar> for G1Projective (g1.rs:518-534, multiply :821-841) and G2Projective (g2.rs:866-886), element-wise:
+ * out_i = [k_i] P_i.  Points uncompressed, scalars 32 bytes big-endian (scalar.rs:229-233) and < r.  A point that does not
+ * decode or is off the curve returns BLSBN254_ERR_G1 / BLSBN254_ERR_G2, a scalar >= r BLSBN254_ERR_SCALAR (the reference's
+ * types make both unrepresentable); the identity and k = 0 give the identity.  Same point as the reference's 255-step
+ * double-and-add, computed with 4-bit windows over the complete RCB formulas.  Not constant time. */
+int blsbn254_g1_mul_batch(blsbn254_ctx* ctx, const uint8_t* g1 /* n*64 */, const uint8_t* scalars /* n*32 */, size_t n, uint8_t* out /* n*64 */);
+int blsbn254_g2_mul_batch(blsbn254_ctx* ctx, const uint8_t* g2 /* n*128 */, const uint8_t* scalars /* n*32 */, size_t n, uint8_t* out /* n*128 */);
 /* sum_i lambda_i * sig_i with Lagrange coefficients at 0 for the t distinct non-zero ids
  * (Mul<Scalar> g1.rs:518-534 + Sum; Fr arithmetic scalar.rs:523-548) */
 int blsbn254_threshold_combine(blsbn254_ctx* ctx, const uint8_t* ids, const uint8_t* partial_sigs, size_t t, uint8_t out_sig[64]);

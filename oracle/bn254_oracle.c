@@ -1089,6 +1089,31 @@ int oracle_aggregate_sigs(const uint8_t* sigs, size_t n, uint8_t out[64]) {     
   g1_encode(out, g1_to_affine(acc));
   return 0;
 }
+/* impl Sum for G2Projective (g2.rs:579-583) over uncompressed encodings; 3 = a point does not decode or is off the curve */
+int oracle_aggregate_pks(const uint8_t* pks, size_t n, uint8_t out[128]) {
+  init();
+  g2p acc = g2_identity();
+  for (size_t i = 0; i < n; ++i) {
+    g2a q;
+    if (!g2_decode(&q, pks + 128 * i) || !g2_on_curve_affine(q)) return 3;
+    acc = g2_add(acc, g2_from_affine(q));
+  }
+  g2_encode(out, g2_to_affine(acc));
+  return 0;
+}
+/* IETF FastAggregateVerify (min-sig variant): one message signed by n keys.  aggregate = sum pk_i (every pk_i decodes and is on
+ * the curve; proof-of-possession is the caller's precondition), then CoreVerify(aggregate, msg, sig) with its KeyValidate
+ * (not the identity, in the r-torsion).  n == 0 -> invalid. */
+int oracle_fast_aggregate_verify(const uint8_t* pks, size_t n, const uint8_t* msg, size_t msg_len, const uint8_t sig[64],
+                                 const uint8_t* dst, size_t dst_len, int* valid) {
+  init();
+  *valid = 0;
+  if (n == 0) return 0;
+  uint8_t agg[128];
+  if (oracle_aggregate_pks(pks, n, agg)) return 0;
+  *valid = verify_one(agg, msg, msg_len, sig, dst, dst_len);
+  return 0;
+}
 int oracle_fr_lagrange_at_zero(const uint8_t* ids, size_t t, uint8_t* out) {
   init();
   fr* lam = (fr*)malloc(sizeof(fr) * (t ? t : 1));

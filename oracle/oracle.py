@@ -150,6 +150,20 @@ def aggregate_sigs(sigs, n):
     return o.tobytes()
 
 
+def aggregate_pks(pks, n):
+    """impl Sum for G2Projective (g2.rs:579-583)"""
+    a, pa = _buf(pks); o, po = _out(128)
+    _chk(lib().oracle_aggregate_pks(pa, ctypes.c_size_t(n), po))
+    return o.tobytes()
+
+
+def fast_aggregate_verify(pks, n, msg, sig, dst):
+    a, pa = _buf(pks); m, pm = _buf(msg); s, ps = _buf(sig); d, pd = _buf(dst)
+    v = ctypes.c_int(0)
+    _chk(lib().oracle_fast_aggregate_verify(pa, ctypes.c_size_t(n), pm, ctypes.c_size_t(len(msg)), ps, pd, ctypes.c_size_t(len(dst)), ctypes.byref(v)))
+    return bool(v.value)
+
+
 def threshold_combine(ids, sigs, t):
     a, pa = _buf(ids); s, ps = _buf(sigs); o, po = _out(64)
     _chk(lib().oracle_threshold_combine(pa, ps, ctypes.c_size_t(t), po))

@@ -282,6 +282,22 @@ void hs_g1_mul(const uint8_t* a, const uint8_t* k_be, uint8_t* out) {
   for (int i = 0; i < 4; ++i) { uint64_t v = 0; for (int j = 0; j < 8; ++j) v = (v << 8) | k_be[8 * (3 - i) + j]; k[i] = v; }
   g1_encode(out, g1_to_affine(proj_mul_256(proj_from_affine(p), k)));
 }
+// Mul<Scalar> with 4-bit windows (proj_mul_win4, curve.h): what blsbn254_g1_mul_batch / g2_mul_batch run per lane
+static void hs_scalar_words(const uint8_t* k_be, uint64_t k[4]) {
+  for (int i = 0; i < 4; ++i) { uint64_t v = 0; for (int j = 0; j < 8; ++j) v = (v << 8) | k_be[8 * (3 - i) + j]; k[i] = v; }
+}
+void hs_g1_mul_win4(const uint8_t* a, const uint8_t* k_be, uint8_t* out) {
+  bool o1;
+  G1A p = g1_decode(a, o1);
+  uint64_t k[4]; hs_scalar_words(k_be, k);
+  g1_encode(out, g1_to_affine(proj_mul_win4(proj_from_affine(p), k)));
+}
+void hs_g2_mul_win4(const uint8_t* a, const uint8_t* k_be, uint8_t* out) {
+  bool o1;
+  G2A p = g2_decode(a, o1);
+  uint64_t k[4]; hs_scalar_words(k_be, k);
+  g2_encode(out, g2_to_affine(proj_mul_win4(proj_from_affine(p), k)));
+}
 // full single verify as the kernels compose it
 int hs_verify(const uint8_t* pk, const uint8_t* msg, size_t len, const uint8_t* sig, const uint8_t* dst, uint32_t dst_len,
               uint8_t* ml_out) {

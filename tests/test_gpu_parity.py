@@ -1101,3 +1101,141 @@ def test_multi_miller_loop_over_prepared_keys(eng, oracle, pyref, M):
     with pytest.raises(M.InvalidG1Bytes):
         eng.multi_miller_loop_prepared(prep, [0], b"\xff" * 64, 1)
     prep.close(); bad.close()
+
+
+# ---- group operations on caller-supplied points and FastAggregateVerify -------------------------
+def _neg_g2(pk):
+    """(x, -y) of an uncompressed G2 point"""
+    yc1 = int.from_bytes(pk[64:96], "big"); yc0 = int.from_bytes(pk[96:128], "big")
+    return pk[:64] + ((synth.P - yc1) % synth.P).to_bytes(32, "big") + ((synth.P - yc0) % synth.P).to_bytes(32, "big")
+
+
+def test_g1_g2_mul_batch_vs_oracle(eng, oracle, pyref, M):
+    """Mul<Scalar> (g1.rs:518-534, g2.rs:866-886) element-wise == the oracle's double-and-add: random points and scalars, the
+    scalars 0, 1, r - 1, the identity as input, a point of E'(Fp2) outside the r-torsion; errors for off-curve points and
+    scalars >= r."""
+    rnd = random.Random(4100)
+    R = pyref.R
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    n = 70
+    ks = [0, 1, R - 1, 2, (1 << 252) + 5] + [rnd.randrange(R) for _ in range(n - 5)]
+    p1 = [oracle.g1_mul(G1, rnd.randrange(1, R)) for _ in range(n)]
+    p2 = [oracle.g2_mul(G2, rnd.randrange(1, R)) for _ in range(n)]
+    p1[7] = IDENT1; p2[7] = IDENT2
+    p2[9] = synth.NON_SUBGROUP_PK                       # Mul works on any curve point
+    kb = b"".join(k.to_bytes(32, "big") for k in ks)
+    got1 = eng.g1_mul_batch(b"".join(p1), kb, n)
+    got2 = eng.g2_mul_batch(b"".join(p2), kb, n)
+    for i in range(n):
+        assert got1[64 * i:64 * i + 64] == oracle.g1_mul(p1[i], ks[i]), i
+        assert got2[128 * i:128 * i + 128] == oracle.g2_mul(p2[i], ks[i]), i
+    assert got1[:64] == IDENT1 and got2[:128] == IDENT2                       # k = 0
+    assert got1[64 * 7:64 * 8] == IDENT1 and got2[128 * 7:128 * 8] == IDENT2  # identity in
+    assert eng.g1_mul_batch(b"", b"", 0) == b"" and eng.g2_mul_batch(b"", b"", 0) == b""
+    off1 = G1[:32] + (3).to_bytes(32, "big")
+    with pytest.raises(M.InvalidG1Bytes):
+        eng.g1_mul_batch(p1[0] + off1, kb[:64], 2)
+    off2 = G2[:96] + (int.from_bytes(G2[96:], "big") ^ 1).to_bytes(32, "big")
+    with pytest.raises(M.InvalidG2Bytes):
+        eng.g2_mul_batch(off2, kb[32:64], 1)
+    with pytest.raises(M.InvalidScalarBytes):
+        eng.g1_mul_batch(p1[0], R.to_bytes(32, "big"), 1)
+    with pytest.raises(M.InvalidScalarBytes):
+        eng.g2_mul_batch(p2[0], b"\xff" * 32, 1)
+    # sk_to_pk is the same operator on the generator
+    assert eng.g2_mul_batch(G2 * 4, kb[32 * 5:32 * 9], 4) == eng.sk_to_pk_batch(kb[32 * 5:32 * 9], 4)
+
+
+def test_aggregate_pks_vs_oracle(eng, oracle, pyref, M):
+    """impl Sum for G2Projective (g2.rs:579-583) over n = 0 ... 5000 points (every chunk-boundary case of the 16-point levels):
+    == the oracle's running sum, == [sum sk] G2gen; identity and repeated terms, a term outside the subgroup; off-curve -> error."""
+    R = pyref.R
+    n_max = 5000
+    sks = [synth.sk_of(3000 + k) for k in range(n_max)]
+    pk_all = eng.sk_to_pk_batch(b"".join(s.to_bytes(32, "big") for s in sks), n_max)
+    assert eng.aggregate_pks(b"", 0) == IDENT2
+    for n in (1, 2, 15, 16, 17, 255, 256, 257, 4097, n_max):
+        got = eng.aggregate_pks(pk_all[:128 * n], n)
+        assert got == oracle.sk_to_pk(sum(sks[:n]) % R), n
+        if n <= 257:
+            assert got == oracle.aggregate_pks(pk_all[:128 * n], n)
+    pk0, pk1 = pk_all[:128], pk_all[128:256]
+    mix = pk0 + IDENT2 + pk1 + pk0 + synth.NON_SUBGROUP_PK + _neg_g2(pk1)
+    assert eng.aggregate_pks(mix, 6) == oracle.aggregate_pks(mix, 6)
+    assert eng.aggregate_pks(pk0 + _neg_g2(pk0), 2) == IDENT2
+    bad = pk0 + pk1[:96] + (int.from_bytes(pk1[96:], "big") ^ 1).to_bytes(32, "big")
+    with pytest.raises(M.InvalidG2Bytes):
+        eng.aggregate_pks(bad, 2)
+    with pytest.raises(M.InvalidG2Bytes):
+        eng.aggregate_pks(pk0 * 20 + b"\xff" * 128 + pk1 * 20, 41)
+
+
+def test_fast_aggregate_verify_vs_oracle(eng, oracle, pyref, M):
+    """One message signed by many keys, group by group == the oracle's FastAggregateVerify: group sizes around the chunk
+    boundaries, tampered message, a foreign key, an off-curve key, a key outside the subgroup, an identity key among valid
+    ones, keys that cancel to the identity, a group without keys, a repeated key (signed twice)."""
+    dst = M.DEFAULT_DST
+    R = pyref.R
+    sizes = [1, 2, 16, 17, 33, 300]
+    groups = []                                       # (key bytes, message, signature)
+    base = 0
+    for gi, sz in enumerate(sizes):
+        sks = [synth.sk_of(5000 + base + k) for k in range(sz)]
+        base += sz
+        skb = b"".join(s.to_bytes(32, "big") for s in sks)
+        pkb = eng.sk_to_pk_batch(skb, sz)
+        msg = synth.msg_of(9000 + gi) + bytes(gi)
+        sig = eng.aggregate_sigs(eng.sign_batch(skb, [msg] * sz, dst), sz)
+        assert sig == oracle.sign(sum(sks) % R, msg, dst)
+        groups.append((pkb, msg, sig))
+    pk17, m17, s17 = groups[3]
+    pk2, m2, s2 = groups[1]
+    stranger = oracle.sk_to_pk(synth.sk_of(1))
+    cases = list(groups)
+    cases.append((pk17, b"tampered", s17))
+    cases.append((pk17[:128 * 16] + stranger, m17, s17))                                   # a foreign key in place of the last
+    cases.append((pk17[:128 * 5] + pk17[128 * 5:128 * 6 - 1] + bytes([pk17[128 * 6 - 1] ^ 1]) + pk17[128 * 6:], m17, s17))   # off-curve key
+    cases.append((pk17 + synth.NON_SUBGROUP_PK, m17, s17))                                 # sum leaves the r-torsion
+    cases.append((pk17[:128 * 9] + IDENT2 + pk17[128 * 9:], m17, s17))                    # an identity term does not change the sum
+    cases.append((pk2[:128] + _neg_g2(pk2[:128]), m2, s2))                                 # keys cancel: the sum is the identity
+    cases.append((b"", m2, s2))                                                            # no key at all
+    sk_a = synth.sk_of(77)
+    pk_a = oracle.sk_to_pk(sk_a)
+    cases.append((pk_a + pk_a, b"twice", oracle.sign(2 * sk_a % R, b"twice", dst)))         # a repeated key counts twice
+    cases.append((pk17, m17, IDENT1))                                                      # identity signature
+    want = [oracle.fast_aggregate_verify(k, len(k) // 128, m, s, dst) for k, m, s in cases]
+    assert want == [True] * 6 + [False, False, False, False, True, False, False, True, False]
+    got = eng.fast_aggregate_verify_batch([k for k, _, _ in cases], [m for _, m, _ in cases], b"".join(s for _, _, s in cases), dst)
+    assert got == synth.bitmap_of(want)
+    for (k, m, s), w in zip(cases, want):
+        assert eng.fast_aggregate_verify(k, len(k) // 128, m, s, dst) is w
+    assert eng.fast_aggregate_verify_batch([], [], b"", dst) == b""
+
+
+def test_fast_aggregate_verify_batch_validator_shape(eng, oracle, pyref, M):
+    """4096 aggregates of 64 keys each (262 144 keys): GPU-signed, every 7th group's message tampered; bitmap == closed form,
+    spot groups == the oracle."""
+    dst = M.DEFAULT_DST
+    R = pyref.R
+    g, per = 4096, 64
+    pool = 1024
+    sks = [synth.sk_of(k) for k in range(pool)]
+    skb = b"".join(s.to_bytes(32, "big") for s in sks)
+    pk_pool = eng.sk_to_pk_batch(skb, pool)
+    key_sets, msgs, sig_list, exp = [], [], [], []
+    agg_sk = []
+    for i in range(g):
+        lo = (i * 37) % (pool - per)
+        key_sets.append(pk_pool[128 * lo:128 * (lo + per)])
+        agg_sk.append(sum(sks[lo:lo + per]) % R)
+        msgs.append(synth.msg_of(20000 + i))
+    sigs = bytearray(eng.sign_batch(b"".join(s.to_bytes(32, "big") for s in agg_sk), msgs, dst))       # [sum sk] H(msg) = sum of the members' signatures
+    for i in range(g):
+        ok = i % 7 != 6
+        if not ok:
+            msgs[i] = b"x" + msgs[i][1:]
+        exp.append(ok)
+    got = eng.fast_aggregate_verify_batch(key_sets, msgs, bytes(sigs), dst)
+    assert got == synth.bitmap_of(exp)
+    for i in (0, 6, 4095):
+        assert oracle.fast_aggregate_verify(key_sets[i], per, msgs[i], bytes(sigs[64 * i:64 * i + 64]), dst) is exp[i]

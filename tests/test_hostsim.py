@@ -100,6 +100,15 @@ def test_hash_checks_and_verify(hs, oracle, pyref, kats):
     hs.hs_g1_add(p, ident, o64); assert o64.raw == p
     k = rnd.randrange(1, pyref.R)
     hs.hs_g1_mul(p, k.to_bytes(32, "big"), o64); assert o64.raw == oracle.g1_mul(p, k)
+    # Mul<Scalar> by 4-bit windows (blsbn254_g1_mul_batch / g2_mul_batch), incl. 0, 1, r - 1, a scalar with zero digits and the identity
+    q2 = oracle.g2_mul(G2, rnd.randrange(1, pyref.R))
+    ident2 = bytes(64) + bytes(32) + (1).to_bytes(32, "big")
+    for kk in (0, 1, pyref.R - 1, 0x1000_0000_0000_0000_0000_0000_0000_0000_f, k):
+        kb = kk.to_bytes(32, "big")
+        hs.hs_g1_mul_win4(p, kb, o64); assert o64.raw == oracle.g1_mul(p, kk)
+        hs.hs_g2_mul_win4(q2, kb, o128); assert o128.raw == oracle.g2_mul(q2, kk)
+    hs.hs_g1_mul_win4(ident, k.to_bytes(32, "big"), o64); assert o64.raw == ident
+    hs.hs_g2_mul_win4(ident2, k.to_bytes(32, "big"), o128); assert o128.raw == ident2
     dst = pyref.DEFAULT_DST
     sk = rnd.randrange(1, pyref.R)
     pk = oracle.sk_to_pk(sk); msg = b"hello"; sig = oracle.sign(sk, msg, dst)
