@@ -207,7 +207,7 @@ def run_rank(args):
         kern = {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in prof.items()}
         # HBM-side bytes per launch of the dominant kernel, from the committed rocprofv3 --pmc passes of this build
         traffic, traffic_note = None, "no PMC profile committed for this batch size"
-        for tname in ("r02_traffic.json", "r01_traffic.json"):
+        for tname in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath) and n == N_PER_GPU:
                 tj = json.load(open(tpath))
@@ -217,6 +217,12 @@ def run_rank(args):
                                     "%.1f KB per tuple against ~0.6 KB algorithmic (sig 64 B, H 108 B, f out 432 B; line tables from cache)"
                                     % (tname, traffic / n / 1024.0))
                     break
+        exec_mads, exec_ratio = None, None
+        epath = os.path.join(ROOT, "profiles", "r03_executed_mads.json")
+        if os.path.exists(epath):
+            for pname, pe in json.load(open(epath)).get("phases", {}).items():
+                if "(k_" + dom + ")" in pname:
+                    exec_mads, exec_ratio = pe["executed_mads"], pe.get("executed_over_algorithmic")
         if world == 1:
             wl = "BASELINE configs[1]"
         else:
@@ -238,17 +244,19 @@ def run_rank(args):
                          "peak_vop2_measured": round(probe["vop2_per_s"] / 1e12, 3),
                          "clock_ghz_under_probe": round(probe["clock_hz_mad"] / 1e9, 3),
                          "traffic": traffic, "traffic_note": traffic_note,
+                         "executed_mads_per_tuple": exec_mads, "executed_over_algorithmic": exec_ratio,
+                         "achieved_executed": None if exec_mads is None else round(exec_mads * n / (mil_ms * 1e-3) / 1e12, 4),
                          "note": "achieved = %d Fp-mul x %d MAD x %d tuples / %.3f ms (HIP events on the engine stream).  Counting "
                                  "convention: Fp-mul = the CPU oracle's textbook count for this kernel's 2-pair loop (squarings count 1; "
-                                 "%s); MADs per "
-                                 "Fp-mul = 136, the 8x32-bit-limb Montgomery product of SURVEY.md 8d.  The kernel's own algorithm needs "
-                                 "fewer products (both lines of a step are folded into f as one product) but executes more MADs "
-                                 "per product (9x29-bit lazy limbs: 162, 243 per double product): executed MADs are ~1.2x the %.2f M counted "
-                                 "per tuple.  peak = v_mad_u64_u32 rate measured in this run at 4 waves/SIMD (blsbn254_valu_probe); "
-                                 "peak_issue_ceiling = CUs x 4 SIMDs x 16 lanes x the clock held under the probe (one VALU instruction "
-                                 "per 4 cycles per SIMD, MI355X_MICROARCH.md).  The path is bound by VALU integer issue, not HBM "
-                                 "(algorithmic traffic ~1.4 KB/verify) and not MFMA"
-                                 % (alg_fp_mul, FP_MUL_MADS, n, mil_ms, count_desc, alg_fp_mul * FP_MUL_MADS / 1e6)},
+                                 "%s); MADs per Fp-mul = 136, the 8x32-bit-limb Montgomery product of SURVEY.md 8d.  executed_mads_per_tuple "
+                                 "= what this kernel's loop really issues per tuple with 9x29-bit lazy limbs (162 per product, 243 per double "
+                                 "product, 9 per linear-combination term), counted by running the device headers on the host with operation "
+                                 "counters (scripts/executed_mads.py -> profiles/r03_executed_mads.json; data independent); achieved_executed "
+                                 "is the same launch priced at that count.  peak = v_mad_u64_u32 rate measured in this run at 4 waves/SIMD "
+                                 "(blsbn254_valu_probe); peak_issue_ceiling = CUs x 4 SIMDs x 16 lanes x the clock held under the probe (one "
+                                 "VALU instruction per 4 cycles per SIMD, MI355X_MICROARCH.md).  The path is bound by VALU integer issue, not "
+                                 "HBM (algorithmic traffic ~1.4 KB/verify) and not MFMA"
+                                 % (alg_fp_mul, FP_MUL_MADS, n, mil_ms, count_desc)},
             "kernel_ms": kern,
             "algorithmic_fp_mul_per_verify": {"miller_variable_pair": core[0], "miller_fixed_pair_lines": core[1], "final_exp": core[2],
                                               "miller_shared_squarings": core[4], "dominant_kernel": alg_fp_mul},

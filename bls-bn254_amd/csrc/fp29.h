@@ -70,7 +70,7 @@ struct Fp {
 
 // ------------------------------------------------------------------ check-mode instrumentation
 #ifdef BN_CHECK
-struct CheckStats { double worst_mul = 0, worst_dot = 0, worst_vb = 0; long muls = 0, sqrs = 0, dots = 0, norms = 0, lcs = 0; };
+struct CheckStats { double worst_mul = 0, worst_dot = 0, worst_vb = 0; long muls = 0, sqrs = 0, dots = 0, norms = 0, lcs = 0, lc_terms = 0; };
 inline CheckStats& check_stats() { static CheckStats s; return s; }
 inline double mag(const Fp& a) { return std::fmax(std::fabs(a.lo), std::fabs(a.hi)); }
 inline double tmag(const Fp& a) { return std::fmax(std::fabs(a.tlo), std::fabs(a.thi)); }
@@ -220,7 +220,7 @@ BN_INL Fp fp_lc4(const Fp& x1, const Fp& x2, const Fp& x3, const Fp& x4) {
   r.l[0] = lo[0];
   BN_UNROLL for (int i = 1; i < NL - 1; ++i) r.l[i] = lo[i] + c[i - 1];
   r.l[NL - 1] = lo[NL - 1] + c[NL - 2] + (c[NL - 1] << RB);     // top limb keeps everything above
-  BN_TRK(++check_stats().lcs;
+  BN_TRK(++check_stats().lcs; check_stats().lc_terms += (K1 != 0) + (K2 != 0) + (K3 != 0) + (K4 != 0) + (REDUCE ? 1 : 0);
          double a1 = lc_abs(K1), a2 = lc_abs(K2), a3 = lc_abs(K3), a4 = lc_abs(K4);
          double m = a1 * mag(x1) + a2 * mag(x2) + a3 * mag(x3) + a4 * mag(x4);            // |t| / L before the q*p term
          double vb = a1 * x1.vb + a2 * x2.vb + a3 * x3.vb + a4 * x4.vb;

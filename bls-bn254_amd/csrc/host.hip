@@ -54,6 +54,7 @@ int blsbn254_ctx_create(int device, blsbn254_ctx** out) {
   c->lanes_per_round = (size_t)prop.multiProcessorCount * 256;
   if (const char* e = std::getenv("BLSBN254_RLC_KEY_ROUND")) c->rlc_key_round = std::atoi(e) != 0;
   if (const char* e = std::getenv("BLSBN254_WIDE_FE")) c->wide_fe = std::atoi(e) != 0;
+  if (const char* e = std::getenv("BLSBN254_SPLIT_EASY")) c->split_easy = std::atoi(e) != 0;
   if (const char* e = std::getenv("BLSBN254_WIDE_FE_MAX")) { long v = std::atol(e); if (v >= 0 && v <= (1 << 20)) c->wide_fe_max = (size_t)v; }
   *out = c;
   return 0;
@@ -223,7 +224,15 @@ int run_final_exp(blsbn254_ctx* c, int32_t* f, size_t n, size_t stride, int mode
   int32_t* S = (int32_t*)c->fe_slots.p;
   int32_t *X = (int32_t*)c->fe[0].p, *A = (int32_t*)c->fe[1].p, *B = (int32_t*)c->fe[2].p, *C = (int32_t*)c->fe[3].p,
           *B2 = (int32_t*)c->fe[4].p, *D = (int32_t*)c->fe[5].p;
-  LAUNCH(c, "fe_easy", k_fe_easy, n, (const int32_t*)f, f, n, stride);                       // t (in place)
+  // t = f^((p^6-1)(p^2+1)), in place.  From a round of waves up, the ONE Fp inversion of the easy part is shared by four tuples
+  // per lane (head / inv4 / tail, k_fe_easy.hip; the pieces wait in the phase buffers A and B, which the hard part only fills later)
+  if (n >= c->lanes_per_round / 2 && c->split_easy) {
+    LAUNCH(c, "fe_easy_head", k_fe_easy_head, n, (const int32_t*)f, n, stride, A, B);
+    LAUNCH(c, "fe_inv4", k_fe_inv4, (n + 3) / 4, B, n, stride);
+    LAUNCH(c, "fe_easy_tail", k_fe_easy_tail, n, (const int32_t*)f, f, n, stride, (const int32_t*)A, (const int32_t*)B);
+  } else {
+    LAUNCH(c, "fe_easy", k_fe_easy, n, (const int32_t*)f, f, n, stride);
+  }
   // Few tuples: the lane-per-tuple kernels below would be the latency of one lane's chain (4.5 ms for any n <= 65536); the hard
   // part runs with one WAVE per tuple instead (k_fe_wide.hip): ~0.6 ms per round of CUs x 16 tuples.  Same values.
   if (c->wide_fe && n <= c->wide_fe_max) {

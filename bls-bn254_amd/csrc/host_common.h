@@ -66,6 +66,7 @@ struct blsbn254_ctx {
   DevBuf th_x, th_num, th_den, th_glv, th_part, th_part2;   // threshold combine: ids, partial products, GLV halves, window sums
   DevBuf fe_wide_one;    // validity bytes of the wave-per-tuple final exponentiation (mode 0)
   bool wide_fe = true;               // BLSBN254_WIDE_FE=0 disables the wave-per-tuple hard part
+  bool split_easy = true;            // BLSBN254_SPLIT_EASY=0: the one-launch easy part at every size
   size_t wide_fe_max = 4096;         // ... used for launches of at most this many tuples (BLSBN254_WIDE_FE_MAX)
   DevBuf gs_ws[3], gs_ok[3], gs_start, gs_len, gs_pk;   // segmented G2 sums (host_groupops.hip): items / chunk sums (ping-pong), flags, chunk descriptors, the sums' encodings
   DevBuf fe_slots;       // the ten named powers of the t -> t^x addition chain, 10 x 108 x n limbs

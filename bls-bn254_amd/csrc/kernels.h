@@ -38,6 +38,9 @@ BN_KERNEL k_g1_to_ws_batch(const uint8_t* g1, size_t n, int32_t* h_ws, uint8_t* 
 BN_KERNEL k_g1_to_ws(const uint8_t* g1, int32_t* h_ws, size_t slot, size_t stride, uint8_t* ok);
 BN_KERNEL k_miller_verify(const uint8_t* pks, const uint8_t* sigs, const int32_t* h_ws, size_t n, int32_t* f_ws, uint8_t* flags);
 BN_KERNEL k_fe_easy(const int32_t* in, int32_t* out, size_t n, size_t stride);
+BN_KERNEL k_fe_easy_head(const int32_t* in, size_t n, size_t stride, int32_t* head, int32_t* nu);
+BN_KERNEL k_fe_inv4(int32_t* nu, size_t n, size_t stride);
+BN_KERNEL k_fe_easy_tail(const int32_t* in, int32_t* out, size_t n, size_t stride, const int32_t* head, const int32_t* nu);
 BN_KERNEL k_fe_expx(const int32_t* in, int32_t* out, int32_t* slots, size_t n, size_t stride);
 BN_KERNEL k_fe_expx_h1(const int32_t* in, int32_t* slots, size_t n, size_t stride, int32_t* a_out, int32_t* b_out);
 BN_KERNEL k_fe_expx_h2(const int32_t* in, int32_t* slots, size_t n, size_t stride, int32_t* b_in, int32_t* c_out, int32_t* b2_out, int32_t* d2_out);

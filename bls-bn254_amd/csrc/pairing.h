@@ -404,6 +404,54 @@ BN_FUNC Fp12 fe_easy(const Fp12& f) {
   Fp12 t = fp12_mul(fp12_conj(f), fp12_inv(f));
   return fp12_mul(fp12_frob<2>(t), t);
 }
+// The easy part with its ONE Fp inversion taken out (k_fe_easy.hip, three launches): the inversion is ~60 % of fe_easy's
+// instructions, and with one tuple per lane every lane pays it.  Split at the inversion, the middle launch inverts FOUR
+// tuples' norms per lane by Montgomery's trick (3 + 6 products around one a^(p-2)), a quarter of the lanes.
+//   fe_easy_head:  everything of fp12_inv (fp12.rs:212-219 -> fp6.rs:261-287 -> fp2.rs:161-166) before the inversion:
+//                  the three Fp2 cofactors c0, c1, c2 of the Fp6 inverse, the Fp2 norm N, and nu = N.c0^2 + N.c1^2 in Fp
+//   fp_inv4:       nu_i^-1 for four values with one inversion (a zero stays zero: inv0, E15)
+//   fe_easy_tail:  the rest: f^-1 from the parked pieces and nu^-1, then t = conj(f) f^-1, t^(p^2) t
+// Same field values as fe_easy, hence the same canonical limbs.
+struct FeEasyHead { Fp2 c0, c1, c2, nrm; Fp nu; };
+BN_FUNC FeEasyHead fe_easy_head(const Fp12& a) {
+  BN_CTX;
+  Fp6 s0 = fp6_sqr(a.c0), s1 = fp6_sqr(a.c1);
+  Fp6 d = {fp2_sub_mul_xi(s0.c0, s1.c2), fp2_norm(fp2_sub(s0.c1, s1.c0)), fp2_norm(fp2_sub(s0.c2, s1.c1))};
+  Fp2 q0 = fp2_sqr(d.c0), q1 = fp2_sqr(d.c1), q2 = fp2_sqr(d.c2);
+  Fp2 m01 = fp2_mul(d.c0, d.c1), m02 = fp2_mul(d.c0, d.c2), m12 = fp2_mul(d.c1, d.c2);
+  FeEasyHead h;
+  h.c0 = fp2_sub_mul_xi(q0, m12);
+  h.c1 = fp2_norm(fp2_sub(fp2_mul_xi(q2), m01));
+  h.c2 = fp2_norm(fp2_sub(q1, m02));
+  Fp2 u = fp2_add(fp2_mul(d.c2, h.c1), fp2_mul(d.c1, h.c2));
+  h.nrm = fp2_add_mul_xi(fp2_mul(d.c0, h.c0), u);
+  h.nu = fp_dot2(h.nrm.c0, h.nrm.c0, h.nrm.c1, h.nrm.c1);
+  return h;
+}
+BN_FUNC Fp12 fe_easy_tail(const Fp12& a, const FeEasyHead& h, const Fp& nu_inv) {
+  BN_CTX;
+  Fp2 ti = {fp_mul(h.nrm.c0, nu_inv), fp_mul(fp_neg(h.nrm.c1), nu_inv)};      // N^-1 = conj(N) / nu
+  Fp6 t6 = {fp2_mul(h.c0, ti), fp2_mul(h.c1, ti), fp2_mul(h.c2, ti)};         // d^-1
+  Fp12 inv = {fp6_mul(a.c0, t6), fp6_norm(fp6_neg(fp6_mul(a.c1, t6)))};
+  Fp12 t = fp12_mul(fp12_conj(a), inv);
+  return fp12_mul(fp12_frob<2>(t), t);
+}
+// x_i^-1, i < 4, with one inversion; x_i must be multiplication outputs (or normalised)
+BN_FUNC void fp_inv4(Fp x[4]) {
+  BN_CTX;
+  bool z[4];
+  Fp v[4], pre[4];
+  for (int i = 0; i < 4; ++i) { z[i] = fp_is_zero(x[i]); v[i] = fp_select(z[i], fp_one(), fp_norm(x[i])); }
+  pre[0] = v[0];
+  for (int i = 1; i < 4; ++i) pre[i] = fp_mul(pre[i - 1], v[i]);
+  Fp inv = fp_inv(pre[3]);
+  for (int i = 3; i >= 1; --i) {
+    Fp r = fp_mul(inv, pre[i - 1]);
+    inv = fp_mul(inv, v[i]);
+    x[i] = fp_select(z[i], fp_zero(), r);
+  }
+  x[0] = fp_select(z[0], fp_zero(), inv);
+}
 // x0 = t^x  ->  a = t^-2x, b = t^-6x
 BN_FUNC void fe_h1(const Fp12& x0, Fp12& a, Fp12& b) {
   a = fp12_cyclotomic_sqr(fp12_conj(x0));

@@ -103,6 +103,31 @@ int hs_final_exp(const uint8_t* in, uint8_t* out) {
   fp12_to_be(out, final_exponentiation(f));
   return 0;
 }
+// the easy part split at its Fp inversion (k_fe_easy_head / k_fe_inv4 / k_fe_easy_tail) == fe_easy; the inversion is taken
+// with three other values in the same fp_inv4 call (a zero among them must stay zero and must not disturb the others)
+int hs_fe_easy_split_matches(const uint8_t* in, int slot) {
+  bool ok;
+  Fp12 f = fp12_from_be(in, ok);
+  if (!ok) return -1;
+  int32_t head[72], nu[9];
+  const FeEasyHead h = fe_easy_head(f);
+  fp2_store_limbs(head, 1, h.c0); fp2_store_limbs(head + 18, 1, h.c1); fp2_store_limbs(head + 36, 1, h.c2); fp2_store_limbs(head + 54, 1, h.nrm);
+  store_fp(nu, 1, h.nu);
+  Fp x[4];
+  for (int t = 0; t < 4; ++t) x[t] = t == slot ? load_fp(nu, 1) : t == (slot + 1) % 4 ? fp_zero() : t == (slot + 2) % 4 ? fp_one() : fp_mul(load_fp(nu, 1), load_fp(nu, 1));
+  fp_inv4(x);
+  if (!fp_is_zero(x[(slot + 1) % 4]) || !fp_eq(x[(slot + 2) % 4], fp_one())) return -2;
+  if (!fp_eq(fp_mul(fp_mul(x[(slot + 3) % 4], load_fp(nu, 1)), load_fp(nu, 1)), fp_one())) return -3;
+  int32_t inv[9];
+  store_fp(inv, 1, x[slot]);
+  FeEasyHead g;
+  g.c0 = fp2_load_limbs(head, 1); g.c1 = fp2_load_limbs(head + 18, 1); g.c2 = fp2_load_limbs(head + 36, 1); g.nrm = fp2_load_limbs(head + 54, 1);
+  g.nu = fp_zero();
+  uint8_t a[384], b[384];
+  fp12_to_be(a, fe_easy_tail(f, g, load_fp(inv, 1)));
+  fp12_to_be(b, fe_easy(f));
+  return std::memcmp(a, b, 384) == 0 ? 1 : 0;
+}
 // wide.h (one wave per tuple) under the interval checker: the 64 lanes of a phase run one after the other over a host
 // array standing in for the wave's LDS region.  Final exponentiation = serial easy part + wide hard part.
 static void wide_put(const Wide& W, uint32_t v, const Fp12& f) {
@@ -360,4 +385,49 @@ void hs_stats(double* out) {
   out[3] = (double)s.muls; out[4] = (double)s.sqrs; out[5] = (double)s.dots; out[6] = (double)s.norms; out[7] = (double)s.lcs;
 }
 void hs_stats_reset() { check_stats() = CheckStats(); }
+// Executed operation counts of the two dominant loops as the KERNELS run them (data independent: one run counts for all inputs):
+// out[6 k + 0..5] = fp_mul, fp_sqr, fp_dot2, fp_norm, fp_lc passes, fp_lc terms of phase k:
+//   k = 0 miller_loop_prepared (k_miller_prepared)      k = 1 miller_loop_verify_ws2 (k_miller_verify, exact path)
+//   k = 2 cyclotomic_exp_x_chain (one t^x launch)       k = 3 fe_easy        k = 4 fe_h1 + fe_h2 + fe_h3 (the glue steps)
+// Executed MADs follow as 162 mul + 126 sqr + 243 dot2 + 9 lc-terms (scripts/executed_mads.py).
+void hs_executed_ops(const uint8_t* sig, const uint8_t* h, const uint8_t* pk, double* out) {
+  bool ok;
+  G1A S = g1_decode(sig, ok), H = g1_decode(h, ok);
+  G2A Q = g2_decode(pk, ok);
+  static int32_t raw[88 * 54], exp_[88 * 162], inv[81], park[54], slots[10 * 108], parkf[108];
+  g2_prepare_lines(Q, Ws{raw, 1, 0, false});
+  for (int t = 0; t < 88; ++t)
+    line_pair_expand(line_from_table(BN_NEG_G2_LINE_TABLE[t]), line_load_limbs(Ws{raw + 54 * t, 1, 0, false}), Ws{exp_ + 162 * t, 1, 0, false});
+  const Ws w = {inv, 1, 0, false};
+  Fp xs = fp_norm(S.x), ys = fp_norm(S.y), X = fp_norm(H.x), Y = fp_norm(H.y), Z = fp_one();
+  fp_store_mem(w, X); fp_store_mem(ws_at(w, 9), Y); fp_store_mem(ws_at(w, 18), Z);
+  fp_store_mem(ws_at(w, 27), fp_mul(xs, X)); fp_store_mem(ws_at(w, 36), fp_mul(ys, Y)); fp_store_mem(ws_at(w, 45), fp_mul(xs, Z));
+  fp_store_mem(ws_at(w, 54), fp_mul(ys, Z)); fp_store_mem(ws_at(w, 63), fp_mul(ys, X)); fp_store_mem(ws_at(w, 72), fp_mul(xs, Y));
+  auto snap = [&](int k) {
+    CheckStats& s = check_stats();
+    out[6 * k + 0] = (double)s.muls; out[6 * k + 1] = (double)s.sqrs; out[6 * k + 2] = (double)s.dots;
+    out[6 * k + 3] = (double)s.norms; out[6 * k + 4] = (double)s.lcs; out[6 * k + 5] = (double)s.lc_terms;
+    check_stats() = CheckStats();
+  };
+  check_stats() = CheckStats();
+  Fp12 f = miller_loop_prepared(w, Ws{exp_, 1, 0, false});
+  snap(0);
+  // the exact path's loop: invariants sig.x, sig.y, h.x, h.y, pk.x, pk.y in `inv` (72 limbs), T parked
+  fp_store_mem(w, xs); fp_store_mem(ws_at(w, 9), ys); fp_store_mem(ws_at(w, 18), X); fp_store_mem(ws_at(w, 27), Y);
+  fp2_store_mem(ws_at(w, 36), fp2_norm(Q.x)); fp2_store_mem(ws_at(w, 54), fp2_norm(Q.y));
+  check_stats() = CheckStats();
+  (void)miller_loop_verify_ws2(w, Ws{park, 1, 0, false}, BN_NEG_G2_LINE_TABLE);
+  snap(1);
+  Fp12 t = fe_easy(f);
+  snap(3);
+  const Ws pk_ws = {parkf, 1, 0, false};
+  Fp12 x0 = cyclotomic_exp_x_chain(t, Ws{slots, 1, 0, false}, &pk_ws);
+  snap(2);
+  Fp12 a, b, c, b2, d2;
+  fe_h1(x0, a, b);
+  fe_h2(cyclotomic_exp_x(b), b, c, b2, d2);
+  check_stats() = CheckStats();
+  fe_h1(x0, a, b); fe_h2(x0, b, c, b2, d2); (void)fe_h3(t, a, c, b2, x0);       // counts only (operands need not be the real chain values)
+  snap(4);
+}
 }

@@ -249,6 +249,19 @@ def test_wide_final_exponentiation_one_wave_per_tuple(hs, oracle, pyref):
         assert a.raw == b.raw == oracle.final_exponentiation(m, 1)
 
 
+def test_easy_part_split_at_its_inversion(hs, oracle, pyref):
+    """fe_easy_head / fp_inv4 / fe_easy_tail (the three launches of the easy part from a round of waves up) == fe_easy, for
+    every position of the tuple among the four that share one inversion, with a zero and a one as neighbours; under the
+    interval checker."""
+    rnd = random.Random(78)
+    G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+    for slot in range(4):
+        m = oracle.miller_loop_batch(oracle.g1_mul(G1, rnd.randrange(1, pyref.R)), oracle.g2_mul(G2, rnd.randrange(1, pyref.R)), 1)
+        assert hs.hs_fe_easy_split_matches(m, slot) == 1, slot
+    one = (1).to_bytes(32, "big") + bytes(352)
+    assert hs.hs_fe_easy_split_matches(one, 0) == 1
+
+
 def test_wide_miller_loops_over_prepared_keys(hs, oracle, pyref):
     """wide.h Miller loops (R <- R^2, R <- R * L with L assembled by five lanes from the key's table): the one-pair loop equals
     miller_loop_1prepared and the oracle's Miller value, the verify loop over the pair table equals miller_loop_prepared, byte
