@@ -71,11 +71,11 @@ struct Fp {
 // ------------------------------------------------------------------ check-mode instrumentation
 #ifdef BN_CHECK
 struct CheckStats { double worst_mul = 0, worst_dot = 0, worst_vb = 0; long muls = 0, sqrs = 0, dots = 0, norms = 0, lcs = 0, lc_terms = 0; };
-inline CheckStats& check_stats() { static CheckStats s; return s; }
+inline CheckStats& check_stats() { static thread_local CheckStats s; return s; }    // per thread: tests/hostsim runs the lanes of a quad (tri.h) as threads
 inline double mag(const Fp& a) { return std::fmax(std::fabs(a.lo), std::fabs(a.hi)); }
 inline double tmag(const Fp& a) { return std::fmax(std::fabs(a.tlo), std::fabs(a.thi)); }
 struct CtxStack { const char* name[64]; int line[64]; int n = 0; };
-inline CtxStack& ctx_stack() { static CtxStack s; return s; }
+inline CtxStack& ctx_stack() { static thread_local CtxStack s; return s; }
 struct CtxGuard {
   CtxGuard(const char* f, int l) { CtxStack& s = ctx_stack(); if (s.n < 64) { s.name[s.n] = f; s.line[s.n] = l; } ++s.n; }
   ~CtxGuard() { --ctx_stack().n; }

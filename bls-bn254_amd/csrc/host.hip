@@ -55,6 +55,8 @@ int blsbn254_ctx_create(int device, blsbn254_ctx** out) {
   if (const char* e = std::getenv("BLSBN254_RLC_KEY_ROUND")) c->rlc_key_round = std::atoi(e) != 0;
   if (const char* e = std::getenv("BLSBN254_WIDE_FE")) c->wide_fe = std::atoi(e) != 0;
   if (const char* e = std::getenv("BLSBN254_SPLIT_EASY")) c->split_easy = std::atoi(e) != 0;
+  c->tri_max = c->lanes_per_round / 4;        // four lanes per tuple: one round of waves
+  if (const char* e = std::getenv("BLSBN254_TRI_MAX")) { long v = std::atol(e); if (v >= 0 && v <= (1 << 20)) c->tri_max = (size_t)v; }
   if (const char* e = std::getenv("BLSBN254_WIDE_FE_MAX")) { long v = std::atol(e); if (v >= 0 && v <= (1 << 20)) c->wide_fe_max = (size_t)v; }
   *out = c;
   return 0;
@@ -70,7 +72,7 @@ void blsbn254_ctx_destroy(blsbn254_ctx* c) {
   c->fe_slots.release(); c->fe_wide_one.release();
   for (DevBuf& b : c->gs_ws) b.release();
   for (DevBuf& b : c->gs_ok) b.release();
-  c->gs_start.release(); c->gs_len.release(); c->gs_pk.release();
+  c->gs_start.release(); c->gs_len.release(); c->gs_pk.release(); c->tri_vals.release();
   { DevBuf* tb[] = {&c->th_x, &c->th_num, &c->th_den, &c->th_glv, &c->th_part, &c->th_part2, &c->q_ws}; for (DevBuf* b : tb) b->release(); }
   { DevBuf* rb[] = {&c->rlc_a2, &c->rlc_a, &c->rlc_b, &c->rlc_elig, &c->rlc_f2, &c->rlc_bytes, &c->rlc_neg, &c->rlc_ok, &c->rlc_idx, &c->rlc_cpk, &c->rlc_csig, &c->rlc_ch, &c->rlc_csub, &c->rlc_cbm};
     for (DevBuf* b : rb) b->release(); }
@@ -239,6 +241,16 @@ int run_final_exp(blsbn254_ctx* c, int32_t* f, size_t n, size_t stride, int mode
     uint8_t* one = nullptr;
     if (mode == 0) { HIPCHK(c, c->fe_wide_one.reserve(n)); one = (uint8_t*)c->fe_wide_one.p; }
     LAUNCH_WIDE(c, "fe_hard_wide", k_fe_hard_wide, n, (const int32_t*)f, n, stride, flags, sub_ok, one, d_gt, d_is_one, mode);
+    if (mode == 0) { LAUNCH(c, "pack_bitmap", k_pack_bitmap, n, (const uint8_t*)one, n, d_bitmap); }
+    return 0;
+  }
+  // Between the wave-per-tuple limit and a quarter of a round of lanes: three lanes per tuple (k_tri.hip) -- the lane-per-tuple
+  // kernels below would cost one lane's whole chain (5.4 ms) however few tuples there are.  Same values.
+  if (n <= c->tri_max) {
+    HIPCHK(c, c->tri_vals.reserve(n * TRI_VALUE_LIMBS * 4));
+    uint8_t* one = nullptr;
+    if (mode == 0) { HIPCHK(c, c->fe_wide_one.reserve(n)); one = (uint8_t*)c->fe_wide_one.p; }
+    LAUNCH_TRI(c, "fe_tri_hard", k_fe_tri_hard, n, (const int32_t*)f, n, stride, (int32_t*)c->tri_vals.p, flags, sub_ok, one, d_gt, d_is_one, mode);
     if (mode == 0) { LAUNCH(c, "pack_bitmap", k_pack_bitmap, n, (const uint8_t*)one, n, d_bitmap); }
     return 0;
   }

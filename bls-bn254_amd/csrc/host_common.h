@@ -66,6 +66,8 @@ struct blsbn254_ctx {
   DevBuf th_x, th_num, th_den, th_glv, th_part, th_part2;   // threshold combine: ids, partial products, GLV halves, window sums
   DevBuf fe_wide_one;    // validity bytes of the wave-per-tuple final exponentiation (mode 0)
   bool wide_fe = true;               // BLSBN254_WIDE_FE=0 disables the wave-per-tuple hard part
+  size_t tri_max = 16384;            // launches of wide_fe_max < n <= tri_max tuples run three lanes per tuple (k_tri.hip); BLSBN254_TRI_MAX, 0 = off
+  DevBuf tri_vals;                   // the named values of the tri hard part, TRI_VALUES x 108 x n limbs
   bool split_easy = true;            // BLSBN254_SPLIT_EASY=0: the one-launch easy part at every size
   size_t wide_fe_max = 4096;         // ... used for launches of at most this many tuples (BLSBN254_WIDE_FE_MAX)
   DevBuf gs_ws[3], gs_ok[3], gs_start, gs_len, gs_pk;   // segmented G2 sums (host_groupops.hip): items / chunk sums (ping-pong), flags, chunk descriptors, the sums' encodings
@@ -94,6 +96,11 @@ struct ProfScope {
 };
 #define LAUNCH(ctx, name, kernel, n, ...) do { ProfScope ps_(ctx, name); \
     hipLaunchKernelGGL(kernel, dim3(nblocks(n)), dim3(256), 0, (ctx)->stream, __VA_ARGS__); } while (0); HIPCHK(ctx, hipGetLastError())
+
+// four lanes per element (tri.h): 256-lane workgroups of 64 elements
+#define LAUNCH_TRI(ctx, name, kernel, n, ...) do { ProfScope ps_(ctx, name); \
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(((n) + 63) / 64)), dim3(256), 0, (ctx)->stream, __VA_ARGS__); } while (0); HIPCHK(ctx, hipGetLastError())
+static const size_t TRI_VALUE_LIMBS = 20 * 108;      // tri.h TRI_VALUES x 108
 
 // one workgroup of 64 lanes (one wave) per element: the wave-per-tuple kernels (wide.h)
 #define LAUNCH_WIDE(ctx, name, kernel, n, ...) do { ProfScope ps_(ctx, name); \

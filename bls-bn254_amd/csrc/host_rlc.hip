@@ -66,6 +66,9 @@ int prepared_round(blsbn254_ctx* c, const uint32_t* perm, const uint32_t* kid, c
   if (c->wide_fe && cnt <= c->wide_fe_max) {
     LAUNCH_WIDE(c, "miller_wide_prepared", k_miller_wide_prepared, cnt, perm, kid, sigs, h_ws, h_stride, (const int32_t*)c->prep_table.p, (const uint8_t*)c->prep_ok.p, cnt,
                 (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
+  } else if (cnt <= c->tri_max) {                      // the chunk / fallback rounds: three lanes per (virtual) tuple (k_tri.hip)
+    LAUNCH_TRI(c, "miller_tri_prepared", k_miller_tri_prepared, cnt, perm, kid, sigs, h_ws, h_stride, (const int32_t*)c->prep_table.p, (const uint8_t*)c->prep_ok.p, cnt,
+               (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
   } else {
     LAUNCH(c, "miller_prepared", k_miller_prepared, cnt, perm, kid, sigs, h_ws, h_stride, (const int32_t*)c->prep_table.p, (const uint8_t*)c->prep_ok.p, cnt,
            (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);

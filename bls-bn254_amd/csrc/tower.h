@@ -175,21 +175,25 @@ BN_INL void ws_store(const Ws& w, int k, int32_t v) {
 #ifdef BN_CHECK
 }  // namespace bn
 #include <map>
+#include <mutex>
 namespace bn {
-// check mode: the proven bounds of a parked value travel with its address
+// check mode: the proven bounds of a parked value travel with its address (one table for all threads: the lanes of a quad,
+// run as threads by tests/hostsim, read each other's parked values)
 struct ParkTrk { double lo, hi, tlo, thi, vb; };
 inline std::map<const int32_t*, ParkTrk>& park_trk() { static std::map<const int32_t*, ParkTrk> m; return m; }
+inline std::mutex& park_mutex() { static std::mutex m; return m; }
 #endif
 BN_INL Fp fp_load_mem(const Ws& w) {
   Fp r;
   BN_UNROLL for (int k = 0; k < NL; ++k) r.l[k] = ws_load(w, k);
-  BN_TRK(auto it = park_trk().find(ws_addr(w, 0)); if (it == park_trk().end()) check_fail("fp_load_mem of an address never stored", 0);
-         set_trk(r, it->second.lo, it->second.hi, it->second.tlo, it->second.thi, it->second.vb);)
+  BN_TRK(ParkTrk pt; { std::lock_guard<std::mutex> g(park_mutex()); auto it = park_trk().find(ws_addr(w, 0));
+           if (it == park_trk().end()) check_fail("fp_load_mem of an address never stored", 0); pt = it->second; }
+         set_trk(r, pt.lo, pt.hi, pt.tlo, pt.thi, pt.vb);)
   return r;
 }
 BN_INL void fp_store_mem(const Ws& w, const Fp& a) {
   BN_TRK(if (a.lo < -1e-6 || a.hi > 1.0 + 1e-6) check_fail("fp_store_mem needs a normalised value", mag(a));
-         park_trk()[ws_addr(w, 0)] = ParkTrk{a.lo, a.hi, a.tlo, a.thi, a.vb};)
+         { std::lock_guard<std::mutex> g(park_mutex()); park_trk()[ws_addr(w, 0)] = ParkTrk{a.lo, a.hi, a.tlo, a.thi, a.vb}; })
   BN_UNROLL for (int k = 0; k < NL; ++k) ws_store(w, k, a.l[k]);
 }
 BN_INL Fp2 fp2_load_mem(const Ws& w) { return {fp_load_mem(w), fp_load_mem(ws_at(w, 9))}; }

@@ -1,5 +1,6 @@
 """Latency of small calls: verify_batch / pairing_batch / aggregate_verify at n = 1 ... 8192 through the host-pointer C ABI
-(ctypes), with the wave-per-tuple kernels (default) and without (BLSBN254_WIDE_FE=0, BLSBN254_AUTO_PREPARE as given).
+(ctypes): with the wave-per-tuple (n <= 4096) and three-lanes-per-tuple (n <= 16384) kernels (default), with the former only
+(BLSBN254_TRI_MAX=0) and with neither (BLSBN254_WIDE_FE=0, BLSBN254_TRI_MAX=0).
 Usage: python scripts/bench_small.py  -> JSON on stdout"""
 import json, os, sys, time
 sys.path.insert(0, os.getcwd())
@@ -8,17 +9,18 @@ from oracle import oracle as O
 from tests import synth
 
 dst = M.DEFAULT_DST
-sizes = [1, 16, 256, 1024, 4096, 8192]
+sizes = [1, 16, 256, 1024, 4096, 4100, 8192, 16384, 32768]
 out = {}
 e0 = M.Engine(0)
 nmax = max(sizes)
 pks, msgs, sigs, exp = synth.make_batch_gpu(e0, O, nmax, dst, pool=64, invalid_every=0, spot=10)
 g2 = O.g2_generator()
-for label, env in (("wave_per_tuple", None), ("lane_per_tuple", "0")):
-    if env is None:
-        os.environ.pop("BLSBN254_WIDE_FE", None)
-    else:
-        os.environ["BLSBN254_WIDE_FE"] = env
+for label, env, tri in (("wave_and_tri", None, None), ("wave_only", None, "0"), ("lane_per_tuple", "0", "0")):
+    for k, v in (("BLSBN254_WIDE_FE", env), ("BLSBN254_TRI_MAX", tri)):
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     e = M.Engine(0)
     res = {}
     for n in sizes:

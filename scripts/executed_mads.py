@@ -20,7 +20,7 @@ def main():
     src = [os.path.join(SIM, "hostsim.cpp")] + [os.path.join(ROOT, "bls-bn254_amd", "csrc", f)
                                                for f in os.listdir(os.path.join(ROOT, "bls-bn254_amd", "csrc")) if f.endswith(".h")]
     if not os.path.exists(so) or any(os.path.getmtime(p) > os.path.getmtime(so) for p in src):
-        subprocess.check_call(["g++", "-O1", "-std=c++17", "-DBN_CHECK", "-DBN_VERIFY_PARK_T", "-fPIC", "-shared", "-o", so, os.path.join(SIM, "hostsim.cpp")])
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-DBN_CHECK", "-DBN_VERIFY_PARK_T", "-fPIC", "-shared", "-pthread", "-o", so, os.path.join(SIM, "hostsim.cpp")])
     hs = ctypes.CDLL(so)
     from oracle import oracle as O
     from tests import synth

@@ -8,11 +8,50 @@
 #include "../../bls-bn254_amd/csrc/lane_ops.h"
 #include "../../bls-bn254_amd/csrc/keygen.h"
 #include "../../bls-bn254_amd/csrc/glv.h"
+#include "../../bls-bn254_amd/csrc/tri.h"
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include "../../bls-bn254_amd/csrc/wide.h"
 #include <vector>
 #include <cstring>
 
 using namespace bn;
+
+// ---- tri.h on the host: the four lanes of a quad run as four threads; a DPP fetch is a rendezvous (publish, barrier, read, barrier)
+namespace {
+struct TriQuad {
+  bn::Fp slot[4];
+  std::mutex m; std::condition_variable cv; int arrived = 0; long gen = 0;
+  void barrier() {
+    std::unique_lock<std::mutex> lk(m);
+    const long g = gen;
+    if (++arrived == 4) { arrived = 0; ++gen; cv.notify_all(); }
+    else cv.wait(lk, [&] { return gen != g; });
+  }
+};
+thread_local TriQuad* tri_quad = nullptr;
+thread_local uint32_t tri_quad_role = 0;
+// run fn(role) on the four lanes; results are whatever fn writes
+void tri_run(const std::function<void(uint32_t)>& fn) {
+  TriQuad q;
+  std::thread th[4];
+  for (uint32_t r = 0; r < 4; ++r) th[r] = std::thread([&, r] { tri_quad = &q; tri_quad_role = r; fn(r); });
+  for (auto& t : th) t.join();
+}
+}  // namespace
+namespace bn {
+uint32_t tri_host_role() { return tri_quad_role; }
+Fp tri_host_fetch(const Fp& x, int p0, int p1, int p2, int p3) {
+  const int perm[4] = {p0, p1, p2, p3};
+  tri_quad->slot[tri_quad_role] = x;
+  tri_quad->barrier();
+  Fp r = tri_quad->slot[perm[tri_quad_role]];
+  tri_quad->barrier();
+  return r;
+}
+}  // namespace bn
 
 extern "C" {
 
@@ -378,6 +417,82 @@ void hs_glv_phi(const uint8_t* g1, uint8_t* out64) {
   bool ok; G1A p = g1_decode(g1, ok);
   p.x = fp_mul(p.x, fp_const(bnc::GLV_BETA));
   g1_encode(out64, p);
+}
+// tri.h primitives against their serial counterparts: op 0 a*b, 1 a^2, 2 cyclotomic square (a cyclotomic), 3 conj, 4..6 Frobenius^1..3
+int hs_tri_op(int op, const uint8_t* a, const uint8_t* b, uint8_t* out_tri, uint8_t* out_serial) {
+  bool ok1, ok2 = true;
+  Fp12 x = fp12_from_be(a, ok1), y = b ? fp12_from_be(b, ok2) : fp12_one();
+  if (!ok1 || !ok2) return 4;
+  Fp6 res[4];
+  tri_run([&](uint32_t role) {
+    const Fp6 xa = fp6_norm(role == 0 ? x.c0 : x.c1), yb = fp6_norm(role == 0 ? y.c0 : y.c1);      // lanes 2, 3 hold lane 1's half (don't care)
+    Fp6 r;
+    switch (op) {
+      case 0: r = tri_mul(xa, yb, role); break;
+      case 1: r = tri_sqr(xa, role); break;
+      case 2: r = tri_cyc_sqr(xa, role); break;
+      case 3: r = tri_conj(xa, role); break;
+      case 4: r = tri_frob<1>(xa, role); break;
+      case 5: r = tri_frob<2>(xa, role); break;
+      default: r = tri_frob<3>(xa, role); break;
+    }
+    res[role] = r;
+  });
+  fp12_to_be(out_tri, Fp12{res[0], res[1]});
+  Fp12 want;
+  switch (op) {
+    case 0: want = fp12_mul(x, y); break;
+    case 1: want = fp12_sqr(x); break;
+    case 2: want = fp12_cyclotomic_sqr(x); break;
+    case 3: want = fp12_conj(x); break;
+    case 4: want = fp12_frob<1>(x); break;
+    case 5: want = fp12_frob<2>(x); break;
+    default: want = fp12_frob<3>(x); break;
+  }
+  fp12_to_be(out_serial, want);
+  return 0;
+}
+// the verify Miller loop over the pair table on a quad == miller_loop_prepared (bytes of the Miller value); H homogeneous with Z = z_small
+int hs_tri_miller(const uint8_t* sig, const uint8_t* h, const uint8_t* pk, int z_small, uint8_t* out_tri, uint8_t* out_serial) {
+  bool ok;
+  G1A S = g1_decode(sig, ok), H = g1_decode(h, ok);
+  G2A Q = g2_decode(pk, ok);
+  static int32_t raw[88 * 54], exp_[88 * 162], inv[81];
+  g2_prepare_lines(Q, Ws{raw, 1, 0, false});
+  for (int t = 0; t < 88; ++t)
+    line_pair_expand(line_from_table(BN_NEG_G2_LINE_TABLE[t]), line_load_limbs(Ws{raw + 54 * t, 1, 0, false}), Ws{exp_ + 162 * t, 1, 0, false});
+  Fp z = fp_one();
+  for (int k = 1; k < z_small; ++k) z = fp_norm(fp_add(z, fp_one()));
+  z = fp_canon(z);
+  const Ws w = {inv, 1, 0, false};
+  Fp xs = fp_norm(S.x), ys = fp_norm(S.y), X = fp_mul(fp_norm(H.x), z), Y = fp_mul(fp_norm(H.y), z), Z = z;
+  fp_store_mem(w, X); fp_store_mem(ws_at(w, 9), Y); fp_store_mem(ws_at(w, 18), Z);
+  fp_store_mem(ws_at(w, 27), fp_mul(xs, X)); fp_store_mem(ws_at(w, 36), fp_mul(ys, Y)); fp_store_mem(ws_at(w, 45), fp_mul(xs, Z));
+  fp_store_mem(ws_at(w, 54), fp_mul(ys, Z)); fp_store_mem(ws_at(w, 63), fp_mul(ys, X)); fp_store_mem(ws_at(w, 72), fp_mul(xs, Y));
+  fp12_to_be(out_serial, miller_loop_prepared(w, Ws{exp_, 1, 0, false}));
+  Fp6 res[4];
+  tri_run([&](uint32_t role) { res[role] = tri_miller_prepared(w, Ws{exp_, 1, 0, false}, role); });
+  fp12_to_be(out_tri, Fp12{res[0], res[1]});
+  return 0;
+}
+// the hard part on a quad after the serial easy part == final_exponentiation; also the per-lane comparison with one
+int hs_tri_final_exp(const uint8_t* in, uint8_t* out, int* is_one) {
+  bool ok;
+  Fp12 f = fp12_from_be(in, ok);
+  if (!ok) return 4;
+  const Fp12 t = fe_easy(f);
+  static int32_t tw[108];
+  fp12_store_limbs(tw, 1, t);                       // canonical limbs, as k_fe_easy leaves them
+  std::vector<int32_t> vals(TRI_VALUES * 108, 0);
+  Fp6 res[4]; bool half[4];
+  tri_run([&](uint32_t role) {
+    const Fp6 th = tri_load_canon(Ws{tw, 1, 0, false}, role);
+    res[role] = tri_fe_hard(th, Ws{vals.data(), 1, 0, false}, role);
+    half[role] = tri_half_is_one(res[role], role);
+  });
+  fp12_to_be(out, Fp12{res[0], res[1]});
+  *is_one = (half[0] && half[1]) ? 1 : 0;
+  return 0;
 }
 void hs_stats(double* out) {
   CheckStats& s = check_stats();

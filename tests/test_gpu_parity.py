@@ -1239,3 +1239,38 @@ def test_fast_aggregate_verify_batch_validator_shape(eng, oracle, pyref, M):
     assert got == synth.bitmap_of(exp)
     for i in (0, 6, 4095):
         assert oracle.fast_aggregate_verify(key_sets[i], per, msgs[i], bytes(sigs[64 * i:64 * i + 64]), dst) is exp[i]
+
+
+def test_three_lanes_per_tuple_kernels_equal_lane_per_tuple(oracle, pyref, M, monkeypatch):
+    """k_tri.hip (three lanes per tuple: launches of 4097 ... 16384 tuples) == the lane-per-tuple kernels (BLSBN254_TRI_MAX=0) == the
+    expectation: verify_batch on the prepared-key path (Miller loop + hard part on quads), the RLC path (its chunk and fallback
+    rounds), and pairing_batch (the final exponentiation alone on quads, Gt bytes) at sizes around both switch-overs."""
+    dst = M.DEFAULT_DST
+    e_tri = M.Engine(0)
+    monkeypatch.setenv("BLSBN254_TRI_MAX", "0")
+    e_ref = M.Engine(0)
+    monkeypatch.delenv("BLSBN254_TRI_MAX")
+    try:
+        n_max = 16385
+        pks, msgs, sigs, exp = synth.make_batch_gpu(e_ref, oracle, n_max, dst, pool=37, invalid_every=5, spot=20)
+        for n in (4097, 6000, 16384, 16385):
+            want = synth.bitmap_of(exp[:n])
+            a, b, c = pks[:128 * n], msgs[:n], sigs[:64 * n]
+            assert e_tri.verify_batch(a, b, c, dst) == want, n
+            assert e_ref.verify_batch(a, b, c, dst) == want, n
+        n = 9000
+        assert e_tri.verify_batch_rlc(pks[:128 * n], msgs[:n], sigs[:64 * n], dst) == synth.bitmap_of(exp[:n])
+        rnd = random.Random(4242)
+        G1, G2 = oracle.g1_generator(), oracle.g2_generator()
+        m = 4099
+        ks = b"".join(rnd.randrange(1, pyref.R).to_bytes(32, "big") for _ in range(m))
+        g1 = e_ref.g1_mul_batch(G1 * m, ks, m)
+        g2 = e_ref.g2_mul_batch(G2 * m, ks[::-1], m)
+        gt = e_tri.pairing_batch(g1, g2, m)
+        assert gt == e_ref.pairing_batch(g1, g2, m)
+        for i in (0, 1, m - 1):
+            assert gt[384 * i:384 * i + 384] == oracle.pairing_batch(g1[64 * i:64 * i + 64], g2[128 * i:128 * i + 128], 1)
+        ml = e_ref.miller_loop_batch(g1, g2, m)
+        assert e_tri.final_exponentiation(ml, m) == gt
+    finally:
+        e_tri.close(); e_ref.close()
