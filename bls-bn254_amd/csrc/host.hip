@@ -56,6 +56,8 @@ int blsbn254_ctx_create(int device, blsbn254_ctx** out) {
   if (const char* e = std::getenv("BLSBN254_WIDE_FE")) c->wide_fe = std::atoi(e) != 0;
   if (const char* e = std::getenv("BLSBN254_SPLIT_EASY")) c->split_easy = std::atoi(e) != 0;
   c->tri_max = c->lanes_per_round / 4;        // four lanes per tuple: one round of waves
+  if (const char* e = std::getenv("BLSBN254_TRI_MILLER")) c->tri_miller = std::atoi(e) != 0;
+  if (const char* e = std::getenv("BLSBN254_TRI_FE")) c->tri_fe = std::atoi(e) != 0;
   if (const char* e = std::getenv("BLSBN254_TRI_MAX")) { long v = std::atol(e); if (v >= 0 && v <= (1 << 20)) c->tri_max = (size_t)v; }
   if (const char* e = std::getenv("BLSBN254_WIDE_FE_MAX")) { long v = std::atol(e); if (v >= 0 && v <= (1 << 20)) c->wide_fe_max = (size_t)v; }
   *out = c;
@@ -246,7 +248,7 @@ int run_final_exp(blsbn254_ctx* c, int32_t* f, size_t n, size_t stride, int mode
   }
   // Between the wave-per-tuple limit and a quarter of a round of lanes: three lanes per tuple (k_tri.hip) -- the lane-per-tuple
   // kernels below would cost one lane's whole chain (5.4 ms) however few tuples there are.  Same values.
-  if (n <= c->tri_max) {
+  if (n <= c->tri_max && c->tri_fe) {
     HIPCHK(c, c->tri_vals.reserve(n * TRI_VALUE_LIMBS * 4));
     uint8_t* one = nullptr;
     if (mode == 0) { HIPCHK(c, c->fe_wide_one.reserve(n)); one = (uint8_t*)c->fe_wide_one.p; }

@@ -67,6 +67,7 @@ struct blsbn254_ctx {
   DevBuf fe_wide_one;    // validity bytes of the wave-per-tuple final exponentiation (mode 0)
   bool wide_fe = true;               // BLSBN254_WIDE_FE=0 disables the wave-per-tuple hard part
   size_t tri_max = 16384;            // launches of wide_fe_max < n <= tri_max tuples run three lanes per tuple (k_tri.hip); BLSBN254_TRI_MAX, 0 = off
+  bool tri_miller = true, tri_fe = true;   // BLSBN254_TRI_MILLER=0 / BLSBN254_TRI_FE=0: keep one of the two on the lane-per-tuple kernels (A/B runs)
   DevBuf tri_vals;                   // the named values of the tri hard part, TRI_VALUES x 108 x n limbs
   bool split_easy = true;            // BLSBN254_SPLIT_EASY=0: the one-launch easy part at every size
   size_t wide_fe_max = 4096;         // ... used for launches of at most this many tuples (BLSBN254_WIDE_FE_MAX)

@@ -66,7 +66,7 @@ int prepared_round(blsbn254_ctx* c, const uint32_t* perm, const uint32_t* kid, c
   if (c->wide_fe && cnt <= c->wide_fe_max) {
     LAUNCH_WIDE(c, "miller_wide_prepared", k_miller_wide_prepared, cnt, perm, kid, sigs, h_ws, h_stride, (const int32_t*)c->prep_table.p, (const uint8_t*)c->prep_ok.p, cnt,
                 (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
-  } else if (cnt <= c->tri_max) {                      // the chunk / fallback rounds: three lanes per (virtual) tuple (k_tri.hip)
+  } else if (cnt <= c->tri_max && c->tri_miller) {     // the chunk / fallback rounds: three lanes per (virtual) tuple (k_tri.hip)
     LAUNCH_TRI(c, "miller_tri_prepared", k_miller_tri_prepared, cnt, perm, kid, sigs, h_ws, h_stride, (const int32_t*)c->prep_table.p, (const uint8_t*)c->prep_ok.p, cnt,
                (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
   } else {
@@ -96,6 +96,12 @@ static int rlc2_chunk_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* 
     const size_t r0 = (n / G + u + R - 1) / R;
     for (size_t g = G + 1; r0 > 1 && g <= 2 * G; ++g)
       if ((n / g + u + R - 1) / R < r0) { G = g; break; }
+    // ... and up to tri_max virtual tuples the round runs three lanes per tuple (k_tri.hip: less than half the latency of the
+    // lane-per-tuple kernels): a chunk-count bound just above that limit is worth slightly larger chunks (262144 tuples over
+    // 1024 keys: G = 18 -> at most 15587 chunks instead of 17408)
+    if (c->tri_miller && c->tri_fe && c->tri_max > c->wide_fe_max && n / G + u > c->tri_max)
+      for (size_t g = G + 1; g <= 2 * G; ++g)
+        if (n / g + u <= c->tri_max) { G = g; break; }
   }
   const size_t nblk = (n + 255) / 256;
   const uint32_t G32 = (uint32_t)G, n32 = (uint32_t)n, u32 = (uint32_t)u;

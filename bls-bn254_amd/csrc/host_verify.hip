@@ -45,7 +45,7 @@ int verify_prepared_dev(blsbn254_ctx* c, const int32_t* table, const uint8_t* ke
   if (c->wide_fe && n <= c->wide_fe_max) {            // few tuples: one wave per tuple (k_miller_wide.hip), same values
     LAUNCH_WIDE(c, "miller_wide_prepared", k_miller_wide_prepared, n, (const uint32_t*)perm, d_kid, d_sigs, (const int32_t*)c->h_ws.p, n, table, key_ok, n,
                 (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
-  } else if (n <= c->tri_max) {                        // mid-size launches: three lanes per tuple (k_tri.hip), same values
+  } else if (n <= c->tri_max && c->tri_miller) {       // mid-size launches: three lanes per tuple (k_tri.hip), same values
     LAUNCH_TRI(c, "miller_tri_prepared", k_miller_tri_prepared, n, (const uint32_t*)perm, d_kid, d_sigs, (const int32_t*)c->h_ws.p, n, table, key_ok, n,
                (int32_t*)c->f_ws.p, (uint8_t*)c->flags.p);
   } else {

@@ -44,7 +44,7 @@ BN_INL Fp fp_pick(bool c, const Fp& a, const Fp& b) {
 #ifdef BN_CHECK
   return c ? a : b;
 #else
-  return fp_pick(c, a, b);
+  return fp_select(c, a, b);
 #endif
 }
 BN_INL Fp2 fp2_pick(bool c, const Fp2& a, const Fp2& b) { return {fp_pick(c, a.c0, b.c0), fp_pick(c, a.c1, b.c1)}; }
@@ -121,20 +121,24 @@ BN_FUNC Fp6 tri_cyc_sqr(const Fp6& h, uint32_t role) {
 // 54 role .. 54 role + 53 (so the layout IS the one-lane-per-tuple layout of fp12_store_limbs: c0 first).  Lanes 2, 3 of a
 // quad read lane 1's half (any valid address will do) and never store.
 BN_INL uint32_t tri_arole(uint32_t role) { return role < 1u ? 0u : 1u; }
+// A workspace reference moved by a LANE-DEPENDENT number of limbs: the offset goes into the per-lane byte offset.  (ws_at moves
+// the base, which buffer addressing keeps in scalar registers: a base that differs between the lanes of a wave would have to be
+// serialised lane by lane.)  limbs * stride * 4 must fit 32 bits together with the lane's own offset.
+BN_INL Ws ws_at_lane(const Ws& w, uint32_t limbs) { return {w.base, w.stride, w.lane4 + limbs * (uint32_t)w.stride * 4u, w.buf}; }
 // canonical limbs: the exchange format with the one-lane-per-tuple kernels (f_ws, the easy part's output)
 BN_INL Fp6 tri_load_canon(const Ws& w, uint32_t role) {
-  const Ws h = ws_at(w, 54u * tri_arole(role));
+  const Ws h = ws_at_lane(w, 54u * tri_arole(role));
   return {fp2_load_limbs(h), fp2_load_limbs(ws_at(h, 18)), fp2_load_limbs(ws_at(h, 36))};
 }
 BN_INL void tri_store_canon(const Ws& w, const Fp6& a, uint32_t role) {
   if (role < 2u) {
-    const Ws h = ws_at(w, 54u * role);
+    const Ws h = ws_at_lane(w, 54u * role);
     fp2_store_limbs(h, a.c0); fp2_store_limbs(ws_at(h, 18), a.c1); fp2_store_limbs(ws_at(h, 36), a.c2);
   }
 }
 // normalised limbs as they are (no canonicalisation): the named values of the hard part
-BN_INL Fp6 tri_load(const Ws& w, uint32_t role) { return fp6_load_mem(ws_at(w, 54u * tri_arole(role))); }
-BN_INL void tri_store(const Ws& w, const Fp6& a, uint32_t role) { if (role < 2u) fp6_store_mem(ws_at(w, 54u * role), a); }
+BN_INL Fp6 tri_load(const Ws& w, uint32_t role) { return fp6_load_mem(ws_at_lane(w, 54u * tri_arole(role))); }
+BN_INL void tri_store(const Ws& w, const Fp6& a, uint32_t role) { if (role < 2u) fp6_store_mem(ws_at_lane(w, 54u * role), a); }
 // lane 0: c0 == 1, lane 1: c1 == 0; other lanes: true
 BN_INL bool tri_half_is_one(const Fp6& a, uint32_t role) {
   const bool z = fp_is_zero(fp_sub(a.c0.c0, fp_pick(role == 0u, fp_one(), fp_zero()))) & fp_is_zero(a.c0.c1) & fp2_is_zero(a.c1) & fp2_is_zero(a.c2);
@@ -154,12 +158,12 @@ BN_FUNC Fp6 tri_line_pair(const Ws& e, const Ws& cw, uint32_t role) {
   const uint32_t ta1 = odd ? 7u : 2u, ca1 = odd ? 6u : 3u, tb1 = odd ? 8u : 2u, cb1 = odd ? 1u : 0u;      // lane 0: T2 xsX alone (second term zeroed)
   const uint32_t ta2 = odd ? 0u : 3u, ca2 = odd ? 0u : 5u, tb2 = odd ? 0u : 4u, cb2 = odd ? 0u : 0u;      // lane 1: no third coefficient
   const Fp zero = fp_zero();
-  const Fp s1b = fp_pick(odd, fp_load_mem(ws_at(cw, 9u * cb1)), zero);
-  const Fp s2a = fp_pick(odd, zero, fp_load_mem(ws_at(cw, 9u * ca2))), s2b = fp_pick(odd, zero, fp_load_mem(ws_at(cw, 9u * cb2)));
+  const Fp s1b = fp_pick(odd, fp_load_mem(ws_at_lane(cw, 9u * cb1)), zero);
+  const Fp s2a = fp_pick(odd, zero, fp_load_mem(ws_at_lane(cw, 9u * ca2))), s2b = fp_pick(odd, zero, fp_load_mem(ws_at_lane(cw, 9u * cb2)));
   Fp6 l;
-  l.c0 = fp2_dot_fp(fp2_load_limbs(ws_at(e, 18u * ta0)), fp_load_mem(ws_at(cw, 9u * ca0)), fp2_load_limbs(ws_at(e, 18u * tb0)), fp_load_mem(ws_at(cw, 9u * cb0)));
-  l.c1 = fp2_dot_fp(fp2_load_limbs(ws_at(e, 18u * ta1)), fp_load_mem(ws_at(cw, 9u * ca1)), fp2_load_limbs(ws_at(e, 18u * tb1)), s1b);
-  l.c2 = fp2_dot_fp(fp2_load_limbs(ws_at(e, 18u * ta2)), s2a, fp2_load_limbs(ws_at(e, 18u * tb2)), s2b);
+  l.c0 = fp2_dot_fp(fp2_load_limbs(ws_at_lane(e, 18u * ta0)), fp_load_mem(ws_at_lane(cw, 9u * ca0)), fp2_load_limbs(ws_at_lane(e, 18u * tb0)), fp_load_mem(ws_at_lane(cw, 9u * cb0)));
+  l.c1 = fp2_dot_fp(fp2_load_limbs(ws_at_lane(e, 18u * ta1)), fp_load_mem(ws_at_lane(cw, 9u * ca1)), fp2_load_limbs(ws_at_lane(e, 18u * tb1)), s1b);
+  l.c2 = fp2_dot_fp(fp2_load_limbs(ws_at_lane(e, 18u * ta2)), s2a, fp2_load_limbs(ws_at_lane(e, 18u * tb2)), s2b);
   return l;                                                       // lane 0: l0, lane 1: l1 (c2 = 0); lanes 2, 3: l0's formulas (unused)
 }
 BN_FUNC Fp6 tri_miller_prepared(const Ws& cw, const Ws& ktab_in, uint32_t role) {
