@@ -356,7 +356,12 @@ int blsbn254_aggregate_verify_multi(blsbn254_multi* m, const uint8_t* pks, const
  * zeroed full-length word array and the arrays are summed by ONE ncclAllReduce(ncclSum, ncclUint32) over xGMI
  * (disjoint bit sets: SUM == OR; RCCL has no bitwise op), so that on return d_full_bitmap[g] (4 * ceil(N / 32) bytes
  * on device g, N = sum of counts) holds the bitmap of the whole batch in global order on EVERY device.  librccl is
- * loaded with dlopen at first use (BLSBN254_E_RCCL if absent or on an RCCL error, e.g. one ordinal listed twice). */
+ * loaded with dlopen at first use (BLSBN254_E_RCCL if absent or on an RCCL error, e.g. one ordinal listed twice).
+ * Status: exercised on hardware with a ONE-rank communicator only (the builder's and the pool's test boxes have one GPU;
+ * RCCL rejects a communicator that lists an ordinal twice).  The ndev > 1 branch (ncclCommInitAll over ndev ordinals, grouped
+ * all-reduce, shard placement) has a test that runs as soon as two devices are visible
+ * (tests/test_gpu_sharded.py::test_c_abi_multi_device_resident_rccl_two_gpus); until it has run, treat ndev > 1 here as
+ * unverified and prefer blsbn254_verify_batch_multi (host gather) or one process per GPU with torch.distributed. */
 int blsbn254_verify_batch_multi_dev(blsbn254_multi* m, const uint8_t* const* d_pks, const uint8_t* const* d_msgs,
                                     const uint64_t* const* d_off, const uint8_t* const* d_sigs, const size_t* counts,
                                     const uint8_t* dst, size_t dst_len, uint8_t* const* d_full_bitmap);

@@ -226,6 +226,71 @@ pub fn threshold_combine(ids: &[[u8; 32]], partials: &[[u8; 64]]) -> Result<[u8;
     Ok(out)
 }
 
+// ---------------------------------------------------------------- group operators on the crate's own types
+
+/// Body of `impl Mul<Scalar> for G1Projective` (`g1.rs:518-534`, `multiply :821-841`), element-wise over a slice:
+/// `out[i] = scalars[i] * points[i]`.  Scalars are the 32-byte big-endian encoding (`scalar.rs:229-233`).
+pub fn g1_mul_batch(points: &[G1Affine], scalars: &[[u8; 32]]) -> Result<Vec<G1Affine>, Bn254Error> {
+    assert_eq!(points.len(), scalars.len());
+    let n = points.len();
+    let p: Vec<u8> = points.iter().flat_map(|x| x.to_uncompressed()).collect();
+    let k: Vec<u8> = scalars.iter().flatten().copied().collect();
+    let mut out = vec![0u8; 64 * n];
+    with_ctx(|c| check(unsafe { ffi::blsbn254_g1_mul_batch(c, p.as_ptr(), k.as_ptr(), n, out.as_mut_ptr()) }))?;
+    Ok(out.chunks_exact(64).map(|b| Option::<G1Affine>::from(G1Affine::from_uncompressed(b.try_into().unwrap())).expect("engine output is canonical")).collect())
+}
+
+/// Body of `impl Mul<Scalar> for G2Projective` (`g2.rs:866-886`), element-wise.
+pub fn g2_mul_batch(points: &[G2Affine], scalars: &[[u8; 32]]) -> Result<Vec<G2Affine>, Bn254Error> {
+    assert_eq!(points.len(), scalars.len());
+    let n = points.len();
+    let p: Vec<u8> = points.iter().flat_map(|x| x.to_uncompressed()).collect();
+    let k: Vec<u8> = scalars.iter().flatten().copied().collect();
+    let mut out = vec![0u8; 128 * n];
+    with_ctx(|c| check(unsafe { ffi::blsbn254_g2_mul_batch(c, p.as_ptr(), k.as_ptr(), n, out.as_mut_ptr()) }))?;
+    Ok(out.chunks_exact(128).map(|b| Option::<G2Affine>::from(G2Affine::from_uncompressed(b.try_into().unwrap())).expect("engine output is canonical")).collect())
+}
+
+/// Body of `impl Sum for G2Projective` (`g2.rs:579-583`) over affine public keys: the aggregate public key.
+pub fn aggregate_pks(pks: &[[u8; 128]]) -> Result<[u8; 128], Bn254Error> {
+    let flat: Vec<u8> = pks.iter().flatten().copied().collect();
+    let mut out = [0u8; 128];
+    with_ctx(|c| check(unsafe { ffi::blsbn254_aggregate_pks(c, flat.as_ptr(), pks.len(), out.as_mut_ptr()) }))?;
+    Ok(out)
+}
+
+/// IETF FastAggregateVerify (min-sig): one message signed by all of `pks` (proof of possession is the caller's precondition).
+pub fn fast_aggregate_verify(pks: &[[u8; 128]], msg: &[u8], sig: &[u8; 64], dst: &[u8]) -> bool {
+    let flat: Vec<u8> = pks.iter().flatten().copied().collect();
+    let mut valid: c_int = 0;
+    with_ctx(|c| check(unsafe {
+        ffi::blsbn254_fast_aggregate_verify(c, flat.as_ptr(), pks.len(), msg.as_ptr(), msg.len(), sig.as_ptr(), dst.as_ptr(), dst.len(), &mut valid)
+    }))
+    .expect("invalid inputs yield valid = 0");
+    valid == 1
+}
+
+/// The same for many (key set, message, signature) groups in one call: `groups[g]` = the keys of group g.
+pub fn fast_aggregate_verify_batch(groups: &[&[[u8; 128]]], msgs: &[&[u8]], sigs: &[[u8; 64]], dst: &[u8]) -> Vec<bool> {
+    assert!(groups.len() == msgs.len() && msgs.len() == sigs.len());
+    let n = groups.len();
+    let mut koff = Vec::with_capacity(n + 1);
+    koff.push(0u64);
+    let mut flat: Vec<u8> = Vec::new();
+    for g in groups {
+        for k in g.iter() { flat.extend_from_slice(k); }
+        koff.push((flat.len() / 128) as u64);
+    }
+    let (data, off) = pack(msgs);
+    let sg: Vec<u8> = sigs.iter().flatten().copied().collect();
+    let mut bm = vec![0u8; (n + 7) / 8];
+    with_ctx(|c| check(unsafe {
+        ffi::blsbn254_fast_aggregate_verify_batch(c, flat.as_ptr(), koff.as_ptr(), data.as_ptr(), off.as_ptr(), sg.as_ptr(), n, dst.as_ptr(), dst.len(), bm.as_mut_ptr())
+    }))
+    .expect("per-group failures are reported in the bitmap");
+    bits(&bm, n)
+}
+
 // ---------------------------------------------------------------- repeated signers: keys prepared once (G2Prepared, batched)
 
 /// The line tables of a set of public keys, resident on the GPU (`blsbn254_g2prepared`): what `G2Prepared::from`

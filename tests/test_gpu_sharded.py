@@ -178,6 +178,39 @@ def test_c_abi_multi_device_resident_rccl(oracle):
         assert e.value.code == -5
 
 
+def test_c_abi_multi_device_resident_rccl_two_gpus(oracle):
+    """The N > 1 form of the device-resident entry point: two real ordinals, ncclCommInitAll over both, the grouped
+    ncclAllReduce of the bitmap words and the shard offsets of k_place_bitmap.  Skipped on a one-GPU box (the pool's test boxes
+    have one card; the path is then covered by the one-rank communicator above and by the torch.distributed ranks of bench.py)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL rejects a communicator that lists one ordinal twice")
+    import blsbn254_loader
+    M = blsbn254_loader.load()
+    dst = b"TEST_DST"
+    n, half = 608, 320                                   # shard boundary at a multiple of 32
+    pks, msgs, sigs, exp = synth.make_batch(oracle, n, dst, invalid_every=3, uniq=12)
+    data, off = M.engine.pack_messages(msgs)
+    nwords = (n + 31) // 32
+    bufs = []
+    for g, (lo, hi) in enumerate(((0, half), (half, n))):
+        dev = torch.device("cuda", g)
+        o = (off[lo:hi + 1] - off[lo]).astype(np.int64)
+        bufs.append((torch.frombuffer(bytearray(pks[128 * lo:128 * hi]), dtype=torch.uint8).to(dev),
+                     torch.frombuffer(bytearray(data[int(off[lo]):int(off[hi])]), dtype=torch.uint8).to(dev),
+                     torch.from_numpy(o).to(dev),
+                     torch.frombuffer(bytearray(sigs[64 * lo:64 * hi]), dtype=torch.uint8).to(dev),
+                     torch.full((4 * nwords,), 0x55, dtype=torch.uint8, device=dev)))
+    for g in range(2):
+        torch.cuda.synchronize(g)
+    with M.MultiEngine([0, 1]) as me:
+        me.verify_batch_dev([b[0].data_ptr() for b in bufs], [b[1].data_ptr() for b in bufs], [b[2].data_ptr() for b in bufs],
+                            [b[3].data_ptr() for b in bufs], [half, n - half], [b[4].data_ptr() for b in bufs], dst)
+        for b in bufs:                                   # the whole bitmap, in global order, on EVERY device
+            got = bytes(b[4].cpu().numpy())
+            assert got[:(n + 7) // 8] == synth.bitmap_of(exp) and not any(got[(n + 7) // 8:])
+
+
 def test_bench_spawns_its_own_ranks():
     """plain `python bench.py --gpus 2` (WORLD_SIZE unset): the parent starts two ranks before touching the GPU and relays
     rank 0's line; both ranks rehearse on device 0 over gloo (the real run is one rank per GPU over RCCL)."""

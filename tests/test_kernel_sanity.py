@@ -1,0 +1,40 @@
+"""CPU-only: every kernel in the built library has a real body.  A kernel whose source hits undefined behaviour (an accidental
+self-recursion turned k_miller_tri_prepared into a 15-instruction endless loop during round 3) still compiles and links; only
+its size gives it away before a GPU run hangs on it."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+# kernels that are legitimately tiny (index fills, flag reductions, scans) -- everything else does field arithmetic
+SMALL_OK = ("k_iota", "k_pack_bitmap", "k_prep_unsort", "k_status_reduce", "k_and_reduce", "k_kd_", "k_scan_excl", "k_rlc2_", "k_fp12_mask_one", "k_valu_peak", "k_place_bitmap")
+
+
+def test_no_degenerate_kernels():
+    import blsbn254_loader
+    M = blsbn254_loader.load()
+    path = M.library_path()
+    if not os.path.exists(path):
+        __import__("bls_bn254_amd.build", fromlist=["x"]).build()
+    from kernel_resources import code_objects
+    tmp = tempfile.mkdtemp()
+    sizes = {}
+    for idx, (data, off, size) in enumerate(code_objects(path)):
+        co = os.path.join(tmp, "co_%d.o" % idx)
+        open(co, "wb").write(data[off:off + size])
+        dis = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+        cur = None
+        for line in dis.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1); sizes.setdefault(cur, 0)
+            elif cur and re.match(r"^\s+[a-z_0-9]+", line):
+                sizes[cur] += 1
+    kernels = {k: v for k, v in sizes.items() if re.search(r"\dk_[a-z]", k) or k.startswith("k_")}
+    assert len(kernels) >= 60, sorted(kernels)
+    bad = [(k, v) for k, v in kernels.items() if v < 200 and not any(s in k for s in SMALL_OK)]
+    assert not bad, "suspiciously small kernels (undefined behaviour in the source?): %s" % bad
