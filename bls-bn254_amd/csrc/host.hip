@@ -54,6 +54,7 @@ int blsbn254_ctx_create(int device, blsbn254_ctx** out) {
   c->lanes_per_round = (size_t)prop.multiProcessorCount * 256;
   if (const char* e = std::getenv("BLSBN254_RLC_KEY_ROUND")) c->rlc_key_round = std::atoi(e) != 0;
   if (const char* e = std::getenv("BLSBN254_WIDE_FE")) c->wide_fe = std::atoi(e) != 0;
+  if (const char* e = std::getenv("BLSBN254_QUAD_PREP")) c->quad_prep = std::atoi(e) != 0;
   if (const char* e = std::getenv("BLSBN254_SPLIT_EASY")) c->split_easy = std::atoi(e) != 0;
   c->tri_max = c->lanes_per_round / 4;        // four lanes per tuple: one round of waves
   if (const char* e = std::getenv("BLSBN254_TRI_MILLER")) c->tri_miller = std::atoi(e) != 0;

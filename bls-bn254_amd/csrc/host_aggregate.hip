@@ -62,7 +62,7 @@ static int aggregate_partial_impl(blsbn254_ctx* c, const uint8_t* pks, const uin
     if (u * 2 <= np && u <= PREP_MAX_KEYS) {
       HIPCHK(c, c->prep_table.reserve(64)); HIPCHK(c, c->prep_ok.reserve(u)); HIPCHK(c, c->prep_raw.reserve(u * PREP_RAW_LIMBS * 4));
       HIPCHK(c, fork_stream2(c));
-      LAUNCH2(c, "g2_prepare", k_g2_prepare, 2 * 256 * (size_t)nblocks(u), (const uint8_t*)c->in_a.p, (const uint32_t*)c->kd_keys.p, (uint32_t)u, (int32_t*)c->prep_raw.p, (uint8_t*)c->prep_ok.p);
+      LAUNCH_G2_PREPARE(c, LAUNCH2, (const uint8_t*)c->in_a.p, (const uint32_t*)c->kd_keys.p, u, (int32_t*)c->prep_raw.p, (uint8_t*)c->prep_ok.p);
       HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
       LAUNCH(c, "kd_propagate", k_kd_propagate, np, (const uint32_t*)c->kd_rep.p, (uint32_t)np, (uint32_t)u, (uint32_t*)c->kd_kid.p, (uint32_t*)nullptr);   // no sorting here: no histogram
       prepared = true;
@@ -188,7 +188,7 @@ static int aggregate_verify_grouped(blsbn254_ctx* c, const uint8_t* pks, const u
   HIPCHK(c, hipStreamSynchronize(c->stream));                                   // last_key and the staged copies are consumed
   HIPCHK(c, c->prep_ok.reserve(np)); HIPCHK(c, c->prep_raw.reserve(np * PREP_RAW_LIMBS * 4));
   HIPCHK(c, fork_stream2(c));
-  LAUNCH2(c, "g2_prepare", k_g2_prepare, 2 * 256 * (size_t)nblocks(np), (const uint8_t*)c->in_a.p, (const uint32_t*)c->kd_keys.p, (uint32_t)np, (int32_t*)c->prep_raw.p, (uint8_t*)c->prep_ok.p);
+  LAUNCH_G2_PREPARE(c, LAUNCH2, (const uint8_t*)c->in_a.p, (const uint32_t*)c->kd_keys.p, np, (int32_t*)c->prep_raw.p, (uint8_t*)c->prep_ok.p);
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
   // key ids, key-sorted order
   HIPCHK(c, c->h_ws.reserve(n * 27 * 4)); HIPCHK(c, c->kd_cursor.reserve(4 * (u + 1))); HIPCHK(c, c->kd_perm.reserve(4 * n));

@@ -69,6 +69,7 @@ struct blsbn254_ctx {
   size_t tri_max = 16384;            // launches of wide_fe_max < n <= tri_max tuples run three lanes per tuple (k_tri.hip); BLSBN254_TRI_MAX, 0 = off
   bool tri_miller = true, tri_fe = true;   // BLSBN254_TRI_MILLER=0 / BLSBN254_TRI_FE=0: keep one of the two on the lane-per-tuple kernels (A/B runs)
   DevBuf tri_vals;                   // the named values of the tri hard part, TRI_VALUES x 108 x n limbs
+  bool quad_prep = true;             // per-key preparation with four lanes per key while that fits one round of waves (BLSBN254_QUAD_PREP=0: off)
   bool split_easy = true;            // BLSBN254_SPLIT_EASY=0: the one-launch easy part at every size
   size_t wide_fe_max = 4096;         // ... used for launches of at most this many tuples (BLSBN254_WIDE_FE_MAX)
   DevBuf gs_ws[3], gs_ok[3], gs_start, gs_len, gs_pk;   // segmented G2 sums (host_groupops.hip): items / chunk sums (ping-pong), flags, chunk descriptors, the sums' encodings
@@ -102,6 +103,11 @@ struct ProfScope {
 #define LAUNCH_TRI(ctx, name, kernel, n, ...) do { ProfScope ps_(ctx, name); \
     hipLaunchKernelGGL(kernel, dim3((unsigned)(((n) + 63) / 64)), dim3(256), 0, (ctx)->stream, __VA_ARGS__); } while (0); HIPCHK(ctx, hipGetLastError())
 static const size_t TRI_VALUE_LIMBS = 20 * 108;      // tri.h TRI_VALUES x 108
+// G2Prepared::from for u keys (decode, on-curve, psi subgroup test, 88 line triples): four lanes per key (k_keyprep_quad.hip, half
+// the latency) while the 8 u lanes fit one round of waves, else one lane per key (k_keyprep.hip).  L = LAUNCH or LAUNCH2.
+#define LAUNCH_G2_PREPARE(ctx, L, pks, keys, u, raw, ok) do { \
+    if ((ctx)->quad_prep && 8 * (size_t)(u) <= (ctx)->lanes_per_round) { L(ctx, "g2_prepare", k_g2_prepare_quad, 2 * 256 * (size_t)nblocks(4 * (size_t)(u)), pks, keys, (uint32_t)(u), raw, ok); } \
+    else { L(ctx, "g2_prepare", k_g2_prepare, 2 * 256 * (size_t)nblocks(u), pks, keys, (uint32_t)(u), raw, ok); } } while (0)
 
 // one workgroup of 64 lanes (one wave) per element: the wave-per-tuple kernels (wide.h)
 #define LAUNCH_WIDE(ctx, name, kernel, n, ...) do { ProfScope ps_(ctx, name); \

@@ -13,7 +13,7 @@ extern "C" {
 int prepare_keys_async(blsbn254_ctx* c, const uint8_t* d_pks, const uint32_t* d_keys, size_t u, int32_t* table, uint8_t* key_ok) {
   HIPCHK(c, c->prep_raw.reserve(u * PREP_RAW_LIMBS * 4));
   HIPCHK(c, fork_stream2(c));
-  LAUNCH2(c, "g2_prepare", k_g2_prepare, 2 * 256 * (size_t)nblocks(u), d_pks, d_keys, (uint32_t)u, (int32_t*)c->prep_raw.p, key_ok);
+  LAUNCH_G2_PREPARE(c, LAUNCH2, d_pks, d_keys, u, (int32_t*)c->prep_raw.p, key_ok);
   LAUNCH2(c, "g2_expand", k_g2_expand, u * (size_t)BN_NEG_G2_LINES, (const int32_t*)c->prep_raw.p, (uint32_t)u, table);
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
   return 0;
@@ -146,7 +146,7 @@ int blsbn254_g2_prepare_batch(blsbn254_ctx* c, const uint8_t* pks, size_t u, bls
   HIPCHK(c, p->table.reserve(u1 * PREP_KEY_LIMBS * 4)); HIPCHK(c, p->ok.reserve(u1)); HIPCHK(c, c->in_a.reserve(128 * u1)); HIPCHK(c, p->raw.reserve(u1 * PREP_RAW_LIMBS * 4));
   if (u) HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * u, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync((uint8_t*)c->in_a.p + 128 * u, NEG_G2_BYTES, 128, hipMemcpyHostToDevice, c->stream));
-  LAUNCH(c, "g2_prepare", k_g2_prepare, 2 * 256 * (size_t)nblocks(u1), (const uint8_t*)c->in_a.p, (const uint32_t*)nullptr, (uint32_t)u1, (int32_t*)p->raw.p, (uint8_t*)p->ok.p);
+  LAUNCH_G2_PREPARE(c, LAUNCH, (const uint8_t*)c->in_a.p, (const uint32_t*)nullptr, u1, (int32_t*)p->raw.p, (uint8_t*)p->ok.p);
   LAUNCH(c, "g2_expand", k_g2_expand, u1 * (size_t)BN_NEG_G2_LINES, (const int32_t*)p->raw.p, (uint32_t)u1, (int32_t*)p->table.p);
   hipError_t es = hipStreamSynchronize(c->stream);
   if (es != hipSuccess) { (void)hipDeviceSynchronize(); }       // nothing may still be writing the buffers the owner frees

