@@ -96,7 +96,9 @@ int verify_chunk_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msg
   // Same bitmap as the exact per-tuple path below, which batches of mostly distinct keys keep taking.
   // Small chunks (at most wide_fe_max tuples) take it whatever their keys: with tables, the Miller loop and the final
   // exponentiation can run one WAVE per tuple (k_miller_wide.hip, k_fe_wide.hip) instead of at the latency of one lane.
-  const bool small = c->wide_fe && n <= c->wide_fe_max;
+  // ... and mid-size chunks (up to tri_max tuples) likewise: three lanes per tuple (k_tri.hip) need the tables too, and a launch of
+  // that size is bound by latency, not by the table work (16 384 distinct keys: ~2 ms of preparation against 4 ms saved).
+  const bool small = (c->wide_fe && n <= c->wide_fe_max) || (c->tri_miller && c->tri_fe && n <= c->tri_max);
   if (c->auto_prepare && (n >= 1024 || small)) {
     size_t u = 0;
     int rc = dedup_keys(c, d_pks, n, &u);
