@@ -273,6 +273,8 @@ int miller_to_ws(blsbn254_ctx* c, const uint8_t* d_g1, const uint8_t* d_g2, size
   HIPCHK(c, c->status.reserve(n));
   if (c->wide_fe && n <= c->wide_fe_max / 2) {        // few pairs: one wave per pair (lane 0 runs the G2 point arithmetic); the serial part makes the chain ~2 x a prepared one
     LAUNCH_WIDE(c, "miller_wide_1", k_miller_wide_1, n, d_g1, d_g2, n, (int32_t*)c->f_ws.p, n, (uint8_t*)c->status.p);
+  } else if (n <= c->tri_max && c->tri_miller) {      // mid-size: a quad of lanes per pair (k_tri.hip: line steps four lanes per point, f three lanes per value)
+    LAUNCH_TRI(c, "miller_tri_1", k_miller_tri_1, n, d_g1, d_g2, n, (int32_t*)c->f_ws.p, n, (uint8_t*)c->status.p);
   } else {
     LAUNCH(c, "miller_1", k_miller_1, n, d_g1, d_g2, n, (int32_t*)c->f_ws.p, n, (uint8_t*)c->status.p);
   }

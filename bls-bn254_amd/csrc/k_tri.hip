@@ -4,7 +4,7 @@
 // Same values as k_miller_prepared / k_fe_expx* + k_fe_h3, same workspace formats (f_ws: canonical limbs, c0 then c1), so
 // either form can follow the other.  Tuple = global lane / 4, role = lane & 3 (0: c0, 1: c1, 2: the Karatsuba cross product,
 // 3: idle).  Compile policy: the Miller units' (-DBN_FORCE_INLINE -DBN_LC_MAD), one wave per SIMD.
-#include "tri.h"
+#include "quad.h"
 #include "lane_ops.h"
 #include "kernels.h"
 using namespace bn;
@@ -56,4 +56,26 @@ BN_KERNEL k_fe_tri_hard(const int32_t* t_ws, size_t n, size_t stride, int32_t* v
     else if (mode == 3) *is_one = isone ? 1 : 0;
     else gt_bytes[i] = isone ? 1 : 0;
   }
+}
+
+// ML(P_i, Q_i) from byte inputs with a quad per pair (k_miller_1's arguments and outputs): the line steps four lanes per point
+// (quad.h), the accumulator three lanes per value.  status as lane_miller_1: bit 0 g1 decoded, bit 1 g2 decoded, bit 2 either is
+// the identity; such pairs run on the generators (uniform control flow) and yield 1.
+BN_KERNEL k_miller_tri_1(const uint8_t* g1, const uint8_t* g2, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  if (i >= n) return;
+  const uint32_t role = tri_role();
+  bool ok1, ok2;
+  G1A p = g1_decode(g1 + 64 * i, ok1);
+  G2A q = g2_decode(g2 + 128 * i, ok2);
+  const bool ident = p.inf | q.inf;
+  const bool bad = ident | !ok1 | !ok2;
+  G1A gp; gp.x = fp_one(); gp.y = fp_norm(fp_add(fp_one(), fp_one())); gp.inf = false;
+  p.x = fp_select(bad, gp.x, p.x); p.y = fp_select(bad, gp.y, p.y);
+  q.x = fp2_select(bad, fp2_const(bnc::G2_GEN_X), q.x); q.y = fp2_select(bad, fp2_const(bnc::G2_GEN_Y), q.y); q.inf = false;
+  q.x = fp2_norm(q.x); q.y = fp2_norm(q.y);
+  Fp6 f = tri_miller_1(fp_norm(p.x), fp_norm(p.y), q, role);
+  f = fp6_select(bad, fp6_pick(role == 0u, fp6_one(), fp6_zero()), f);
+  tri_store_canon(Ws{f_ws, f_stride, (uint32_t)i * 4u, true}, f, role);
+  if (role == 0u) status[i] = (uint8_t)((ok1 ? 1 : 0) | (ok2 ? 2 : 0) | (ident ? 4 : 0));
 }

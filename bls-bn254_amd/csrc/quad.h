@@ -201,4 +201,41 @@ BN_FUNC bool quad_torsion_free(const G2A& a, uint32_t role) {
   return a.inf | proj_eq(lhs, rhs);
 }
 
+// ---- the one-pair Miller loop with a VARIABLE G2 point on a quad (miller_loop_1, pairing.h; pairings.rs:760-857): the line steps
+// run four lanes per point (above), the Fp12 accumulator three lanes per value (tri.h).  A line l = c0 py + c1 px w + c2 w^3 is the
+// sparse element (o0, 0, 0) + (o3, o4, 0) w: every lane multiplies ITS Karatsuba operand by a two-coefficient Fp6 (fp6_mul_by_01,
+// five Fp2 products) -- lane 0: f0 (o0, 0), lane 1: f1 (o3, o4), lane 2: (f0 - f1)(o3 - o0, o4) -- then the usual recombination.
+// Same values as ell / fp12_mul_by_034, hence the same canonical Miller value as miller_loop_1 and the oracle.
+BN_FUNC Fp6 tri_ell(const Fp6& f, const Line& l, const Fp& px, const Fp& py, uint32_t role) {
+  BN_CTX;
+  const Fp2 o0 = fp2_mul_fp(l.c0, py), o3 = fp2_mul_fp(l.c1, px);
+  const Fp2 b0 = fp2_pick(role == 0u, o0, fp2_pick(role == 1u, o3, fp2_norm(fp2_sub(o3, o0))));
+  const Fp2 b1 = fp2_pick(role == 0u, fp2_zero(), l.c2);
+  const Fp6 p = fp6_mul_by_01(tri_third<false, false>(f, role), b0, b1);
+  const Fp6 x1 = tri_fetch6<1, 0, 0, 0>(p);
+  const Fp6 x2 = tri_fetch6<2, 2, 2, 2>(p);
+  return tri_recombine(p, x1, fp6_norm(fp6_add(fp6_add(p, x1), x2)), role);
+}
+// p: affine G1 point (normalised coordinates), q: affine G2 point, both validated by the caller and held by every lane
+BN_FUNC Fp6 tri_miller_1(const Fp& px, const Fp& py, const G2A& q, uint32_t role) {
+  BN_CTX;
+  Fp6 f = fp6_norm(fp6_pick(role == 0u, fp6_one(), fp6_zero()));
+  G2J T = {q.x, q.y, fp2_one()};
+  const Fp2 nqy = fp2_norm(fp2_neg(q.y));
+  for (int j = bnc::ATE_NAF_LEN - 2; j >= 0; --j) {
+    f = tri_sqr(f, role);
+    f = tri_ell(f, quad_doubling_step(T, role), px, py, role);
+    const int d = ate_naf_digit(j);
+    if (d != 0) f = tri_ell(f, quad_addition_step(T, q.x, d > 0 ? q.y : nqy, role), px, py, role);
+  }
+  const Fp2 g2 = fp2_const(bnc::GAMMA1[1]), g3 = fp2_const(bnc::GAMMA1[2]);
+  const Fp2 cx = fp2_norm(fp2_conj(q.x)), cy = fp2_norm(fp2_conj(q.y));
+  const Quad4 f1 = quad_products(q_pick4(role, cx, cy, cx, cy), q_pick4(role, g2, g3, g2, g3));          // pi(Q)
+  const Fp2 c1x = fp2_norm(fp2_conj(f1.r0)), c1y = fp2_norm(fp2_conj(f1.r1));
+  const Quad4 f2 = quad_products(q_pick4(role, c1x, c1y, c1x, c1y), q_pick4(role, g2, g3, g2, g3));
+  f = tri_ell(f, quad_addition_step(T, f1.r0, f1.r1, role), px, py, role);
+  f = tri_ell(f, quad_addition_step(T, f2.r0, fp2_norm(fp2_neg(f2.r1)), role), px, py, role);           // -pi^2(Q)
+  return f;
+}
+
 }  // namespace bn

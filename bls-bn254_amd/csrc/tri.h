@@ -48,6 +48,7 @@ BN_INL Fp fp_pick(bool c, const Fp& a, const Fp& b) {
 #endif
 }
 BN_INL Fp2 fp2_pick(bool c, const Fp2& a, const Fp2& b) { return {fp_pick(c, a.c0, b.c0), fp_pick(c, a.c1, b.c1)}; }
+BN_INL Fp6 fp6_select(bool c, const Fp6& a, const Fp6& b) { return {fp2_select(c, a.c0, b.c0), fp2_select(c, a.c1, b.c1), fp2_select(c, a.c2, b.c2)}; }   // data-dependent
 BN_INL Fp6 fp6_pick(bool c, const Fp6& a, const Fp6& b) { return {fp2_pick(c, a.c0, b.c0), fp2_pick(c, a.c1, b.c1), fp2_pick(c, a.c2, b.c2)}; }
 
 // The third Karatsuba operand: lanes 0 and 1 keep their own half x (normalised); lanes 2 (and 3) get x0 + x1 (ADD) or

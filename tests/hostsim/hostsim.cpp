@@ -509,6 +509,20 @@ int hs_quad_prepare(const uint8_t* pk, int* torsion_bits) {
   *torsion_bits = (tf_q[0] ? 1 : 0) | (tf_s ? 2 : 0) | ((tf_q[0] == tf_q[1] && tf_q[1] == tf_q[2] && tf_q[2] == tf_q[3]) ? 4 : 0);
   return std::memcmp(raw_s, raw_q, sizeof raw_s) == 0 ? 1 : 0;
 }
+// ML(P, Q) with a variable G2 point on a quad (tri_miller_1, quad.h) == miller_loop_1: bytes of both
+int hs_tri_miller_1(const uint8_t* g1, const uint8_t* g2, uint8_t* out_tri, uint8_t* out_serial) {
+  bool ok1, ok2;
+  G1A p = g1_decode(g1, ok1);
+  G2A q = g2_decode(g2, ok2);
+  if (!ok1 || !ok2 || p.inf || q.inf) return -1;
+  q.x = fp2_norm(q.x); q.y = fp2_norm(q.y);
+  p.x = fp_norm(p.x); p.y = fp_norm(p.y);
+  fp12_to_be(out_serial, miller_loop_1(p, q));
+  Fp6 res[4];
+  tri_run([&](uint32_t role) { res[role] = tri_miller_1(p.x, p.y, q, role); });
+  fp12_to_be(out_tri, Fp12{res[0], res[1]});
+  return 0;
+}
 void hs_stats(double* out) {
   CheckStats& s = check_stats();
   out[0] = s.worst_mul; out[1] = s.worst_dot; out[2] = s.worst_vb;

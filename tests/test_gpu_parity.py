@@ -1273,5 +1273,16 @@ def test_three_lanes_per_tuple_kernels_equal_lane_per_tuple(oracle, pyref, M, mo
             assert gt[384 * i:384 * i + 384] == oracle.pairing_batch(g1[64 * i:64 * i + 64], g2[128 * i:128 * i + 128], 1)
         ml = e_ref.miller_loop_batch(g1, g2, m)
         assert e_tri.final_exponentiation(ml, m) == gt
+        # the variable-Q Miller loop on quads (k_miller_tri_1): per-pair Miller values, byte for byte, incl. an identity and an
+        # undecodable operand in the middle of the batch
+        ml_tri = e_tri.miller_loop_batch(g1, g2, m)
+        assert ml_tri == ml
+        assert ml_tri[:384 * 2] == oracle.miller_loop_batch(g1[:128], g2[:256], 2)
+        g1b = g1[:64 * 5] + IDENT1 + g1[64 * 6:]
+        assert e_tri.pairing_batch(g1b, g2, m) == e_ref.pairing_batch(g1b, g2, m)
+        assert e_tri.pairing_batch(g1b, g2, m)[384 * 5:384 * 6] == ONE_GT
+        g2b = g2[:128 * 7] + b"\xff" * 128 + g2[128 * 8:]
+        with pytest.raises(M.InvalidG2Bytes):
+            e_tri.pairing_batch(g1, g2b, m)
     finally:
         e_tri.close(); e_ref.close()

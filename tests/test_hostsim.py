@@ -324,3 +324,7 @@ def test_quad_four_lanes_per_key(hs, oracle, pyref):
     for pk in (oracle.sk_to_pk(rnd.randrange(1, pyref.R)), G2):
         assert hs.hs_quad_prepare(pk, ctypes.byref(bits)) == 1 and bits.value == 7
     assert hs.hs_quad_prepare(synth.NON_SUBGROUP_PK, ctypes.byref(bits)) == 1 and bits.value == 4      # same table, both say "outside", all lanes agree
+    # the one-pair Miller loop with a variable G2 point on a quad (quad line steps + three-lane accumulator) == miller_loop_1 == the oracle
+    a = ctypes.create_string_buffer(384); b = ctypes.create_string_buffer(384)
+    g1 = oracle.g1_mul(oracle.g1_generator(), rnd.randrange(1, pyref.R)); g2 = oracle.g2_mul(G2, rnd.randrange(1, pyref.R))
+    assert hs.hs_tri_miller_1(g1, g2, a, b) == 0 and a.raw == b.raw == oracle.miller_loop_batch(g1, g2, 1)
