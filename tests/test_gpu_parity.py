@@ -766,10 +766,12 @@ def test_chunked_prepared_paths(oracle, M, monkeypatch):
         p0, e0 = e.path_stats()
         assert e.verify_batch(pks, msgs, sigs, dst) == want
         # the two full chunks take the prepared path in either mode; the 900-tuple tail takes it as a small chunk (one wave per
-        # tuple) only while the wave-per-tuple kernels are on -- with BLSBN254_WIDE_FE=0 (a documented production knob) a chunk
-        # below 1024 tuples goes down the exact per-tuple path
+        # tuple, or three lanes per tuple) only while those kernels are on -- with BLSBN254_WIDE_FE=0 and BLSBN254_TRI_MAX=0
+        # (documented production knobs) a chunk below 1024 tuples goes down the exact per-tuple path
         wide = os.environ.get("BLSBN254_WIDE_FE", "1") != "0" and int(os.environ.get("BLSBN254_WIDE_FE_MAX", "4096")) >= 900
-        assert e.path_stats() == ((p0 + 3, e0) if wide else (p0 + 2, e0 + 1))
+        tri = (int(os.environ.get("BLSBN254_TRI_MAX", "16384")) >= 900 and os.environ.get("BLSBN254_TRI_MILLER", "1") != "0"
+               and os.environ.get("BLSBN254_TRI_FE", "1") != "0")          # three lanes per tuple read the tables as well
+        assert e.path_stats() == ((p0 + 3, e0) if (wide or tri) else (p0 + 2, e0 + 1))
         keys = sorted(set(pks[128 * i:128 * i + 128] for i in range(n)))
         index = {k: j for j, k in enumerate(keys)}
         prep = e.g2_prepare_batch(b"".join(keys), len(keys))
@@ -934,12 +936,13 @@ def test_prepared_key_path_equals_exact_path(eng, oracle, M, n, pool):
     assert oracle.verify_batch(pks, msgs, sigs, dst, nthreads=16) == want       # ~3 s of CPU at n = 20000
 
 
-@pytest.mark.parametrize("pool,prepared", [(2560, True), (2561, False)])
+@pytest.mark.parametrize("pool,prepared", [(8448, True), (8449, False)])
 def test_prepared_path_threshold(eng, oracle, M, pool, prepared):
-    """the switch-over: a chunk of more than 4096 tuples takes the prepared path exactly when at most half of its public keys
-    are distinct (smaller chunks always do: their Miller loops and final exponentiations run one wave per tuple off the tables)"""
+    """the switch-over: a chunk of more than 16384 tuples takes the prepared path exactly when at most half of its public keys
+    are distinct (smaller chunks always do: their Miller loops and final exponentiations run one wave / three lanes per tuple off
+    the tables, k_miller_wide.hip / k_tri.hip)"""
     dst = M.DEFAULT_DST
-    n = 5120
+    n = 16896
     skb = b"".join(synth.sk_of(k).to_bytes(32, "big") for k in range(pool))
     pkp = eng.sk_to_pk_batch(skb, pool)
     msgs = [synth.msg_of(90000 + i) for i in range(n)]
@@ -954,9 +957,10 @@ def test_prepared_path_threshold(eng, oracle, M, pool, prepared):
 
 
 def test_prepared_path_not_taken_for_distinct_keys(eng, oracle, M):
-    """mostly distinct keys: the de-duplication finds more than n / 2 of them and the exact path runs"""
+    """mostly distinct keys in a chunk beyond the three-lanes-per-tuple limit: the de-duplication finds more than n / 2 of them and
+    the exact path runs (up to 16384 tuples the table path is taken whatever the keys: test_three_lanes_per_tuple_...)"""
     dst = M.DEFAULT_DST
-    n = 4200
+    n = 16500
     sks = [synth.sk_of(k) for k in range(n)]
     pks = eng.sk_to_pk_batch(b"".join(s.to_bytes(32, "big") for s in sks), n)
     msgs = [synth.msg_of(i) for i in range(n)]
