@@ -177,7 +177,8 @@ static int aggregate_verify_grouped(blsbn254_ctx* c, const uint8_t* pks, const u
   size_t u = 0;
   rc = dedup_keys(c, (const uint8_t*)c->in_a.p, n, &u);
   if (rc) return rc;
-  const bool small = c->wide_fe && n + 1 <= c->wide_fe_max;       // few pairs: from tables, one wave per pair, whatever the keys
+  // few pairs: from tables, one wave per pair (or, up to tri_max pairs, a quad of lanes per pair: k_miller_tri_1p), whatever the keys
+  const bool small = (c->wide_fe && n + 1 <= c->wide_fe_max) || (c->tri_miller && n + 1 <= c->tri_max);
   if (!((u * 2 <= n || small) && u + 1 <= PREP_MAX_KEYS)) return 0;
   *took = true;
   const size_t np = u + 1, n_lanes = (np + 1) / 2;
@@ -222,6 +223,9 @@ static int aggregate_verify_grouped(blsbn254_ctx* c, const uint8_t* pks, const u
   if (c->wide_fe && np <= c->wide_fe_max) {           // a handful of keys: one WAVE per pair
     LAUNCH_WIDE(c, "miller_wide_1p", k_miller_wide_1p, np, (const int32_t*)h2, np, (const uint32_t*)kid2, (const int32_t*)c->prep_raw.p, (const uint8_t*)c->prep_ok.p, np,
                 (int32_t*)c->f_ws.p, np, (uint8_t*)c->flags.p, (const uint8_t*)st);
+  } else if (c->tri_miller && np <= c->tri_max) {     // a few thousand pairs: a quad of lanes per pair
+    LAUNCH_TRI(c, "miller_tri_1p", k_miller_tri_1p, np, (const int32_t*)h2, np, (const uint32_t*)kid2, (const int32_t*)c->prep_raw.p, (const uint8_t*)c->prep_ok.p, np,
+               (int32_t*)c->f_ws.p, np, (uint8_t*)c->flags.p, (const uint8_t*)st);
   } else if (one_per_lane) {
     LAUNCH(c, "miller_hpk1p", k_miller_hpk1p, np, (const int32_t*)h2, np, (const uint32_t*)kid2, (const int32_t*)c->prep_raw.p, (const uint8_t*)c->prep_ok.p, np,
            (int32_t*)c->f_ws.p, np, (uint8_t*)c->flags.p, (const uint8_t*)st);

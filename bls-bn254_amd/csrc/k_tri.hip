@@ -79,3 +79,21 @@ BN_KERNEL k_miller_tri_1(const uint8_t* g1, const uint8_t* g2, size_t n, int32_t
   tri_store_canon(Ws{f_ws, f_stride, (uint32_t)i * 4u, true}, f, role);
   if (role == 0u) status[i] = (uint8_t)((ok1 ? 1 : 0) | (ok2 ? 2 : 0) | (ident ? 4 : 0));
 }
+
+// ONE pair (H, pk) per quad with the key's lines read from its prepared raw table: k_miller_hpk1p's arguments and outputs
+// (aggregate verify by per-key sums over a few thousand distinct keys: u + 1 pairs).
+BN_KERNEL k_miller_tri_1p(const int32_t* h_ws, size_t h_stride, const uint32_t* kid, const int32_t* table, const uint8_t* key_ok, size_t n,
+                          int32_t* f_ws, size_t f_stride, uint8_t* flags, const uint8_t* skip) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  if (i >= n) return;
+  const uint32_t role = tri_role();
+  const bool live = !(skip && (skip[i] & 2));
+  const uint32_t key = kid[i];
+  const Ws hw = {const_cast<int32_t*>(h_ws), h_stride, (uint32_t)i * 4u, true};
+  const Fp px = fp_load_mem(hw), py = fp_load_mem(ws_at(hw, 9));
+  const Ws ta = {const_cast<int32_t*>(table), 1, key * (uint32_t)(BN_NEG_G2_LINES * 54 * 4), true};
+  Fp6 f = tri_miller_1prepared(px, py, ta, role);
+  f = fp6_select(live, f, fp6_pick(role == 0u, fp6_one(), fp6_zero()));
+  tri_store_canon(Ws{f_ws, f_stride, (uint32_t)i * 4u, true}, f, role);
+  if (role == 0u) flags[i] = key_ok[key];
+}

@@ -121,6 +121,8 @@ BN_KERNEL k_miller_prepared(const uint32_t* perm, const uint32_t* kid, const uin
 BN_KERNEL k_miller_tri_prepared(const uint32_t* perm, const uint32_t* kid, const uint8_t* sigs, const int32_t* h_ws, size_t h_stride,
                                 const int32_t* table, const uint8_t* key_ok, size_t n, int32_t* f_ws, uint8_t* flags);
 BN_KERNEL k_miller_tri_1(const uint8_t* g1, const uint8_t* g2, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status);
+BN_KERNEL k_miller_tri_1p(const int32_t* h_ws, size_t h_stride, const uint32_t* kid, const int32_t* table, const uint8_t* key_ok, size_t n,
+                          int32_t* f_ws, size_t f_stride, uint8_t* flags, const uint8_t* skip);
 BN_KERNEL k_fe_tri_hard(const int32_t* t_ws, size_t n, size_t stride, int32_t* vals, const uint8_t* flags, const uint8_t* sub_ok,
                         uint8_t* one, uint8_t* gt_bytes, int* is_one, int mode);
 BN_KERNEL k_lagrange_partial(const int32_t* x_ws, size_t t, size_t J, int32_t* pnum, int32_t* pden, uint8_t* dup);

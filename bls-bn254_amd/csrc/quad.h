@@ -238,4 +238,23 @@ BN_FUNC Fp6 tri_miller_1(const Fp& px, const Fp& py, const G2A& q, uint32_t role
   return f;
 }
 
+// One pair with a PREPARED key on a quad (miller_loop_1prepared, pairing.h): f = ML(H, Q), the 88 line triples of Q read from its
+// raw table (54 canonical limbs per line; every lane of the quad loads the triple), H affine (px, py) on every lane.
+BN_FUNC Fp6 tri_miller_1prepared(const Fp& px, const Fp& py, const Ws& ta_in, uint32_t role) {
+  BN_CTX;
+  Fp6 f = fp6_norm(fp6_pick(role == 0u, fp6_one(), fp6_zero()));
+  Ws ta = ta_in;
+  int ti = 0;
+  for (int j = bnc::ATE_NAF_LEN - 2; j >= -2; --j) {               // j = -1, -2: the two final lines (no squaring)
+    if (j >= 0) f = tri_sqr(f, role);
+    const int lines = j >= 0 ? (ate_naf_digit(j) != 0 ? 2 : 1) : 1;
+    for (int q = 0; q < lines; ++q) {
+      BN_OPAQUE(ta);
+      f = tri_ell(f, line_load_limbs(ws_at(ta, 54 * (size_t)ti)), px, py, role);
+      ++ti;
+    }
+  }
+  return f;
+}
+
 }  // namespace bn

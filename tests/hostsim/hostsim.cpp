@@ -523,6 +523,22 @@ int hs_tri_miller_1(const uint8_t* g1, const uint8_t* g2, uint8_t* out_tri, uint
   fp12_to_be(out_tri, Fp12{res[0], res[1]});
   return 0;
 }
+// one pair with a prepared key on a quad (tri_miller_1prepared) == miller_loop_1prepared == ML(H, Q)
+int hs_tri_miller_1prepared(const uint8_t* g1, const uint8_t* g2, uint8_t* out_tri, uint8_t* out_serial) {
+  bool ok1, ok2;
+  G1A p = g1_decode(g1, ok1);
+  G2A q = g2_decode(g2, ok2);
+  if (!ok1 || !ok2 || p.inf || q.inf) return -1;
+  static int32_t raw[88 * 54], hh[18];
+  g2_prepare_lines(q, Ws{raw, 1, 0, false});
+  const Ws hw = {hh, 1, 0, false};
+  fp_store_mem(hw, fp_norm(p.x)); fp_store_mem(ws_at(hw, 9), fp_norm(p.y));
+  fp12_to_be(out_serial, miller_loop_1prepared(hw, Ws{raw, 1, 0, false}));
+  Fp6 res[4];
+  tri_run([&](uint32_t role) { res[role] = tri_miller_1prepared(fp_load_mem(hw), fp_load_mem(ws_at(hw, 9)), Ws{raw, 1, 0, false}, role); });
+  fp12_to_be(out_tri, Fp12{res[0], res[1]});
+  return 0;
+}
 void hs_stats(double* out) {
   CheckStats& s = check_stats();
   out[0] = s.worst_mul; out[1] = s.worst_dot; out[2] = s.worst_vb;

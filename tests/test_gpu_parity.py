@@ -1290,3 +1290,32 @@ def test_three_lanes_per_tuple_kernels_equal_lane_per_tuple(oracle, pyref, M, mo
             e_tri.pairing_batch(g1, g2b, m)
     finally:
         e_tri.close(); e_ref.close()
+
+
+def test_aggregate_verify_mid_size_distinct_keys_on_quads(oracle, pyref, M, monkeypatch):
+    """aggregate_verify over a few thousand DISTINCT keys: every key is prepared (four lanes per key) and every pair runs on a quad
+    of lanes off its key's table (k_miller_tri_1p), one product tree, one final exponentiation == the pairwise lane path
+    (BLSBN254_TRI_MAX=0) == the expectation; tampered message, a key outside the subgroup."""
+    dst = M.DEFAULT_DST
+    e_tri = M.Engine(0)
+    monkeypatch.setenv("BLSBN254_TRI_MAX", "0")
+    e_ref = M.Engine(0)
+    monkeypatch.delenv("BLSBN254_TRI_MAX")
+    try:
+        n = 5000
+        sks = [synth.sk_of(40000 + k) for k in range(n)]
+        skb = b"".join(x.to_bytes(32, "big") for x in sks)
+        pk = e_ref.sk_to_pk_batch(skb, n)
+        ms = [synth.msg_of(50000 + i) for i in range(n)]
+        agg = e_ref.aggregate_sigs(e_ref.sign_batch(skb, ms, dst), n)
+        g0, p0 = e_tri.aggregate_path_stats()
+        assert e_tri.aggregate_verify(pk, ms, agg, dst) is True
+        assert e_tri.aggregate_path_stats() == (g0 + 1, p0)                  # the table path, although no key repeats
+        assert e_ref.aggregate_verify(pk, ms, agg, dst) is True
+        bad = list(ms); bad[n - 3] = b"tampered"
+        assert e_tri.aggregate_verify(pk, bad, agg, dst) is False and e_ref.aggregate_verify(pk, bad, agg, dst) is False
+        pk_bad = pk[:128 * 77] + synth.NON_SUBGROUP_PK + pk[128 * 78:]
+        assert e_tri.aggregate_verify(pk_bad, ms, agg, dst) is False
+        assert e_tri.aggregate_verify(pk, ms, IDENT1, dst) is False
+    finally:
+        e_tri.close(); e_ref.close()

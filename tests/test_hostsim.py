@@ -328,3 +328,4 @@ def test_quad_four_lanes_per_key(hs, oracle, pyref):
     a = ctypes.create_string_buffer(384); b = ctypes.create_string_buffer(384)
     g1 = oracle.g1_mul(oracle.g1_generator(), rnd.randrange(1, pyref.R)); g2 = oracle.g2_mul(G2, rnd.randrange(1, pyref.R))
     assert hs.hs_tri_miller_1(g1, g2, a, b) == 0 and a.raw == b.raw == oracle.miller_loop_batch(g1, g2, 1)
+    assert hs.hs_tri_miller_1prepared(g1, g2, a, b) == 0 and a.raw == b.raw == oracle.miller_loop_batch(g1, g2, 1)     # lines from the key's table
