@@ -1243,6 +1243,21 @@ def test_fast_aggregate_verify_batch_validator_shape(eng, oracle, pyref, M):
     assert got == synth.bitmap_of(exp)
     for i in (0, 6, 4095):
         assert oracle.fast_aggregate_verify(key_sets[i], per, msgs[i], bytes(sigs[64 * i:64 * i + 64]), dst) is exp[i]
+    # 6000 groups of 8 keys: the per-group sums go through the mid-size (three lanes per tuple) verify pipeline
+    g2n, per2 = 6000, 8
+    ks2, ms2, ag2, ex2 = [], [], [], []
+    for i in range(g2n):
+        lo = (i * 13) % (pool - per2)
+        ks2.append(pk_pool[128 * lo:128 * (lo + per2)])
+        ag2.append(sum(sks[lo:lo + per2]) % R)
+        ms2.append(synth.msg_of(40000 + i))
+    sg2 = eng.sign_batch(b"".join(s.to_bytes(32, "big") for s in ag2), ms2, dst)
+    for i in range(g2n):
+        ok = i % 11 != 10
+        if not ok:
+            ms2[i] = bytes([ms2[i][0] ^ 1]) + ms2[i][1:]
+        ex2.append(ok)
+    assert eng.fast_aggregate_verify_batch(ks2, ms2, sg2, dst) == synth.bitmap_of(ex2)
 
 
 def test_three_lanes_per_tuple_kernels_equal_lane_per_tuple(oracle, pyref, M, monkeypatch):
