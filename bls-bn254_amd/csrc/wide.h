@@ -12,7 +12,7 @@
 // phase boundary is a workgroup barrier on the device (the workgroup is one wave) and the end of a loop over the 64 lane
 // ids in tests/hostsim, which runs this same code under the interval checker.
 #pragma once
-#include "pairing.h"
+#include "quad.h"
 
 namespace bn {
 
@@ -186,35 +186,55 @@ BN_HD inline void wide_miller_prepared(const Wide& W, const Ws& table, const Ws&
   }
 }
 
-// The one-pair loop with a VARIABLE G2 point (miller_loop_1, pairing.h; pairings.rs:760-857): lane 0 keeps the running point T
-// and computes each line (doubling_step / addition_step, serial: their Fp2 chains hardly parallelise), parks the triple in LDS
-// at lnw (54 limbs), five lanes evaluate it at P = pt and the whole wave multiplies it in.  q: the validated point (every lane
-// may hold it; lane 0's copy is used).  Result in WV_R.
+// The one-pair loop with a VARIABLE G2 point (miller_loop_1, pairing.h; pairings.rs:760-857): lanes 0 .. 3 keep the running point T
+// and compute each line as a QUAD (quad.h: the independent Fp2 products of every level of doubling_step / addition_step side by
+// side, DPP fetches inside the quad; r02 ran them on lane 0 alone: about half of the kernel's time), lane 0 parks the triple in
+// LDS at lnw (54 limbs), five lanes evaluate it at P = pt and the whole wave multiplies it in.  q: the validated point (every
+// lane holds it).  Result in WV_R.  On the host the quad's phase runs as four threads (tri_host_run4, tests/hostsim).
+#if !defined(__HIP_DEVICE_COMPILE__)
+void tri_host_run4(void (*fn)(void*, uint32_t), void* arg);       // hostsim: run fn(arg, role) on the four lanes of a quad
+struct WideLineStep { G2J* T; const Fp2 *ax, *ay; const Ws* lnw; bool dbl; };
+inline void wide_line_step_host(void* a, uint32_t role) {
+  WideLineStep* w = (WideLineStep*)a;
+  G2J& T = w->T[role];
+  const Line l = fp2_norm_line(w->dbl ? quad_doubling_step(T, role) : quad_addition_step(T, *w->ax, *w->ay, role));
+  if (role == 0u) line_store(*w->lnw, l);
+}
+#endif
 BN_HD inline void wide_miller_1(const Wide& W, const G2A& q, const Ws& pt, const Ws& lnw) {
   BN_WIDE_PHASE(lane,
     if (lane < 6u) fp2_store_mem(wide_val(W, WV_R, lane), lane == 0u ? fp2_one() : fp2_zero());
   )
-  G2J T = {q.x, q.y, fp2_one()};
   const Fp2 nqy = fp2_norm(fp2_neg(q.y));
   const Fp2 g2 = fp2_const(bnc::GAMMA1[1]), g3 = fp2_const(bnc::GAMMA1[2]);
   const Fp2 q1x = fp2_mul(fp2_norm(fp2_conj(q.x)), g2), q1y = fp2_mul(fp2_norm(fp2_conj(q.y)), g3);        // pi(Q)
   const Fp2 q2x = fp2_mul(fp2_norm(fp2_conj(q1x)), g2);
   const Fp2 q2y = fp2_norm(fp2_neg(fp2_mul(fp2_norm(fp2_conj(q1y)), g3)));                                  // -pi^2(Q)
+#if defined(__HIP_DEVICE_COMPILE__)
+  G2J T = {q.x, q.y, fp2_one()};
+#define BN_WIDE_LINE_STEP(DBL, AX, AY) { const uint32_t lane_ = threadIdx.x & 63u; \
+    if (lane_ < 4u) { const Line l_ = fp2_norm_line((DBL) ? quad_doubling_step(T, lane_) : quad_addition_step(T, AX, AY, lane_)); if (lane_ == 0u) line_store(lnw, l_); } \
+    __syncthreads(); }
+#else
+  G2J Tq[4] = {{q.x, q.y, fp2_one()}, {q.x, q.y, fp2_one()}, {q.x, q.y, fp2_one()}, {q.x, q.y, fp2_one()}};
+#define BN_WIDE_LINE_STEP(DBL, AX, AY) { const Fp2 ax_ = (AX), ay_ = (AY); WideLineStep w_ = {Tq, &ax_, &ay_, &lnw, (DBL)}; tri_host_run4(wide_line_step_host, &w_); }
+#endif
   for (int j = bnc::ATE_NAF_LEN - 2; j >= -2; --j) {                // j = -1, -2: the two Frobenius additions
     if (j >= 0) {
       wide_exec(W, WOP_MUL, WV_R, WV_R, WV_R);
-      BN_WIDE_PHASE(lane, if (lane == 0u) line_store(lnw, fp2_norm_line(doubling_step(T))); )
+      BN_WIDE_LINE_STEP(true, q.x, q.y)
       wide_line_eval_1<true>(W, WV_L, lnw, pt);
       wide_exec(W, WOP_MUL, WV_R, WV_R, WV_L);
     }
     const int d = j >= 0 ? ate_naf_digit(j) : 1;
     if (d != 0) {
       const Fp2 ax = j >= 0 ? q.x : j == -1 ? q1x : q2x, ay = j >= 0 ? (d > 0 ? q.y : nqy) : j == -1 ? q1y : q2y;
-      BN_WIDE_PHASE(lane, if (lane == 0u) line_store(lnw, fp2_norm_line(addition_step(T, ax, ay))); )
+      BN_WIDE_LINE_STEP(false, ax, ay)
       wide_line_eval_1<true>(W, WV_L, lnw, pt);
       wide_exec(W, WOP_MUL, WV_R, WV_R, WV_L);
     }
   }
+#undef BN_WIDE_LINE_STEP
 }
 // out = in^x by the addition chain of cyclotomic_exp_x_chain (pairing.h): 62 squarings + 17 products; R is the accumulator
 BN_HD inline void wide_exp_x(const Wide& W, uint32_t out, uint32_t in) {

@@ -43,6 +43,7 @@ void tri_run(const std::function<void(uint32_t)>& fn) {
 }
 }  // namespace
 namespace bn {
+void tri_host_run4(void (*fn)(void*, uint32_t), void* arg) { tri_run([&](uint32_t role) { fn(arg, role); }); }
 uint32_t tri_host_role() { return tri_quad_role; }
 Fp tri_host_fetch(const Fp& x, int p0, int p1, int p2, int p3) {
   const int perm[4] = {p0, p1, p2, p3};
