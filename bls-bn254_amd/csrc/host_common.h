@@ -71,7 +71,8 @@ struct blsbn254_ctx {
   DevBuf tri_vals;                   // the named values of the tri hard part, TRI_VALUES x 108 x n limbs
   bool quad_prep = true;             // per-key preparation with four lanes per key while that fits one round of waves (BLSBN254_QUAD_PREP=0: off)
   bool split_easy = true;            // BLSBN254_SPLIT_EASY=0: the one-launch easy part at every size
-  size_t wide_fe_max = 4096;         // ... used for launches of at most this many tuples (BLSBN254_WIDE_FE_MAX)
+  size_t wide_fe_max = 2048;         // ... used for launches of at most this many tuples (BLSBN254_WIDE_FE_MAX): two rounds of a wave per tuple
+                                     // cost what the three-lanes-per-tuple kernels cost for anything up to 16384 (r03: 4096 wide = 7.8 ms, 4100 on quads = 5.6 ms)
   DevBuf gs_ws[3], gs_ok[3], gs_start, gs_len, gs_pk;   // segmented G2 sums (host_groupops.hip): items / chunk sums (ping-pong), flags, chunk descriptors, the sums' encodings
   DevBuf fe_slots;       // the ten named powers of the t -> t^x addition chain, 10 x 108 x n limbs
   uint8_t dst_host[256];  // the (pre-hashed if oversize) DST currently resident in `dst`, and its length; -1 = none

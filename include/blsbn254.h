@@ -108,14 +108,16 @@ int blsbn254_aggregate_verify(blsbn254_ctx* ctx, const uint8_t* pks, const uint8
  * (multi_miller_loop over prepared terms, pairings.rs:808-857) in key-sorted order.  Same bitmap as the exact
  * per-tuple path, which batches of mostly distinct keys keep taking.  BLSBN254_AUTO_PREPARE=0 in the environment or
  * blsbn254_set_auto_prepare(ctx, 0) forces the exact path; blsbn254_path_stats counts the chunks each path served.
- * Small calls.  A launch of at most 4096 tuples is bound by the latency of one lane's chain, so such calls (verify, pairing,
- * Miller loop, final exponentiation, aggregate verify) run the Miller loop and the hard part of the final exponentiation
- * with one WAVE per tuple (same values, same bytes), and verify chunks of that size take the prepared-key path whatever
- * their keys (the tables are what that Miller loop reads).  BLSBN254_WIDE_FE=0 switches this off,
- * BLSBN254_WIDE_FE_MAX=<n> moves the limit. */
+ * Small and mid-size calls.  A launch that does not fill the chip is bound by the latency of one lane's chain, so such calls
+ * (verify, pairing, Miller loop, final exponentiation, aggregate verify) run the Miller loop and the hard part of the final
+ * exponentiation with one WAVE per tuple up to 2048 tuples and with THREE LANES per tuple (a DPP quad: the three Fp6 products
+ * of an Fp12 product side by side) up to 16384 -- same values, same bytes -- and verify chunks of those sizes take the
+ * prepared-key path whatever their keys (the tables are what those Miller loops read; the per-key preparation itself runs four
+ * lanes per key).  BLSBN254_WIDE_FE=0 / BLSBN254_TRI_MAX=0 switch the two forms off, BLSBN254_WIDE_FE_MAX=<n> /
+ * BLSBN254_TRI_MAX=<n> move the limits, BLSBN254_QUAD_PREP=0 keeps the per-key preparation on one lane per key. */
 int blsbn254_set_auto_prepare(blsbn254_ctx* ctx, int on);
 int blsbn254_path_stats(blsbn254_ctx* ctx, uint64_t out[2] /* prepared, exact */);
-/* blsbn254_aggregate_verify over repeated keys (auto-prepare on; at most half of the n >= 1024 keys distinct, or at most 4095 pairs):
+/* blsbn254_aggregate_verify over repeated keys (auto-prepare on; at most half of the n >= 1024 keys distinct, or at most 16383 pairs):
  * by bilinearity in the first argument  prod_{i: pk_i = pk} e(H(msg_i), pk) = e(sum_i H(msg_i), pk)  -- exact, no randomness --
  * the H(msg_i) of every distinct key are summed in G1 (n additions) and ONE Miller loop per distinct key runs
  * (multi_miller_loop over u + 1 prepared terms, pairings.rs:808-857).  Same boolean; the Miller value differs from the product
@@ -280,7 +282,7 @@ int blsbn254_g2_decompress_batch(blsbn254_ctx* ctx, const uint8_t* in /* n*64 */
  * blsbn254_verify_batch_dev is asynchronous except for ONE 4-byte read-back per chunk: the number of distinct public keys (it sizes
  * the per-key tables and chooses between the prepared-key and the exact per-tuple pipeline), i.e. the call returns once the key
  * de-duplication kernels of its last chunk have run -- everything behind them is still in flight.  Measured cost: the timed step
- * is 0.2 ms longer than the sum of its kernels.  Launch size picks the kernels: up to 4096 tuples one wave per tuple,
+ * is 0.2 ms longer than the sum of its kernels.  Launch size picks the kernels: up to 2048 tuples one wave per tuple,
  * up to 16384 three lanes per tuple, beyond one lane per tuple -- same values, same bitmap. */
 int blsbn254_verify_batch_dev(blsbn254_ctx* ctx, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
                               const uint8_t* d_sigs, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* d_valid_bitmap);

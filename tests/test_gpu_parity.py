@@ -694,8 +694,8 @@ def test_verify_batch_rlc_edge_cases(eng, oracle, pyref, M, monkeypatch):
 
 
 def test_wide_final_exponentiation_equals_serial(eng, oracle, pyref, M, monkeypatch):
-    """Launches of at most 4096 tuples run the hard part of the final exponentiation with one WAVE per tuple
-    (k_fe_wide.hip); larger ones, or BLSBN254_WIDE_FE=0, with one lane per tuple: same Gt bytes, same bitmaps, at the
+    """Launches of at most 2048 tuples run the hard part of the final exponentiation with one WAVE per tuple
+    (k_fe_wide.hip); larger ones three lanes per tuple, or with BLSBN254_WIDE_FE=0 one lane per tuple: same Gt bytes, same bitmaps, at the
     switch-over sizes and through every mode of the finishing step (Gt bytes, verify bitmap, single flag)."""
     rnd = random.Random(4096)
     G1, G2 = oracle.g1_generator(), oracle.g2_generator()
@@ -707,10 +707,10 @@ def test_wide_final_exponentiation_equals_serial(eng, oracle, pyref, M, monkeypa
     serial = M.Engine(0)
     monkeypatch.delenv("BLSBN254_WIDE_FE")
     try:
-        for n in (1, 63, 4096, 4097):
+        for n in (1, 63, 2048, 2049, 4097):
             g1 = b"".join(p1[i % base] for i in range(n)); g2 = b"".join(p2[i % base] for i in range(n))
             exp = b"".join(want[384 * (i % base):384 * (i % base) + 384] for i in range(n))
-            assert eng.pairing_batch(g1, g2, n) == exp                   # wide up to 4096, serial beyond
+            assert eng.pairing_batch(g1, g2, n) == exp                   # wide up to 2048, three lanes per tuple beyond
             if n <= 63:
                 assert serial.pairing_batch(g1, g2, n) == exp            # serial kernels on the small sizes too
         dst = M.DEFAULT_DST
@@ -768,7 +768,7 @@ def test_chunked_prepared_paths(oracle, M, monkeypatch):
         # the two full chunks take the prepared path in either mode; the 900-tuple tail takes it as a small chunk (one wave per
         # tuple, or three lanes per tuple) only while those kernels are on -- with BLSBN254_WIDE_FE=0 and BLSBN254_TRI_MAX=0
         # (documented production knobs) a chunk below 1024 tuples goes down the exact per-tuple path
-        wide = os.environ.get("BLSBN254_WIDE_FE", "1") != "0" and int(os.environ.get("BLSBN254_WIDE_FE_MAX", "4096")) >= 900
+        wide = os.environ.get("BLSBN254_WIDE_FE", "1") != "0" and int(os.environ.get("BLSBN254_WIDE_FE_MAX", "2048")) >= 900
         tri = (int(os.environ.get("BLSBN254_TRI_MAX", "16384")) >= 900 and os.environ.get("BLSBN254_TRI_MILLER", "1") != "0"
                and os.environ.get("BLSBN254_TRI_FE", "1") != "0")          # three lanes per tuple read the tables as well
         assert e.path_stats() == ((p0 + 3, e0) if (wide or tri) else (p0 + 2, e0 + 1))
