@@ -395,9 +395,22 @@ BN_FUNC SvdwFrac svdw_g1_frac(const Fp& u_in) {
 // enter the complete addition as (N : y D : D); the sum stays in homogeneous coordinates.
 BN_FUNC G1P hash_to_g1_from_fields_proj(const Fp& u0, const Fp& u1) {
   BN_CTX;
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BN_HASH_MAP_LOOP)
+  // ONE copy of the map in the instruction stream (a two-trip loop the compiler may not unroll): the inlined map is ~150 KB of
+  // code, and with two waves per SIMD drifting apart two copies thrash the instruction cache (k_hash_to_g1: 23 % of its wave
+  // cycles waited for instructions, profiles/r03_pmc_summary.txt)
+  Fp u[2] = {u0, u1};
+  G1P q[2];
+  _Pragma("unroll 1") for (int k = 0; k < 2; ++k) {
+    const SvdwFrac a = svdw_g1_frac(u[k]);
+    q[k] = G1P{a.n, fp_mul(a.y, a.d), a.d};
+  }
+  return proj_add(q[0], q[1]);
+#else
   const SvdwFrac a = svdw_g1_frac(u0), b = svdw_g1_frac(u1);
   const G1P q0 = {a.n, fp_mul(a.y, a.d), a.d}, q1 = {b.n, fp_mul(b.y, b.d), b.d};
   return proj_add(q0, q1);
+#endif
 }
 BN_FUNC G1A hash_to_g1_from_fields(const Fp& u0, const Fp& u1) { return g1_to_affine(hash_to_g1_from_fields_proj(u0, u1)); }
 
