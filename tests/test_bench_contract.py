@@ -78,3 +78,25 @@ def test_scripts_compile():
     for f in sorted(os.listdir(d)):
         if f.endswith(".py"):
             py_compile.compile(os.path.join(d, f), doraise=True)
+
+
+def test_executed_mads_and_rank_fields_of_the_committed_lines():
+    """roofline.executed_mads_per_tuple is the hostsim count committed beside it (scripts/executed_mads.py), priced consistently;
+    the committed N > 1 rehearsal line carries the per-rank spread and the all-reduce time."""
+    b = json.load(open(_latest("r*_final_bench.json")))
+    r = b["roofline"]
+    if r.get("executed_mads_per_tuple") is not None:
+        e = json.load(open(os.path.join(ROOT, "profiles", "r03_executed_mads.json")))
+        ph = [v for k, v in e["phases"].items() if "(" + r["kernel"] + ")" in k]
+        assert len(ph) == 1 and ph[0]["executed_mads"] == r["executed_mads_per_tuple"]
+        m = e["mads_per_op"]
+        assert ph[0]["executed_mads"] == (m["fp_mul"] * ph[0]["fp_mul"] + m["fp_sqr"] * ph[0]["fp_sqr"] + m["fp_dot2"] * ph[0]["fp_dot2"]
+                                          + m["fp_lc_term"] * ph[0]["fp_lc_terms"])
+        assert abs(r["achieved_executed"] / r["achieved"] - r["executed_over_algorithmic"]) < 0.01
+    n2 = glob.glob(os.path.join(ROOT, "profiles", "r03_n2_rehearsal_one_gpu.json"))
+    if n2:
+        j = json.loads(open(n2[0]).read().strip().splitlines()[-1])
+        assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "cpu_baseline" not in j
+        for k in ("ms_per_step_min", "ms_per_step_max", "allreduce_ms_min", "allreduce_ms_max", "datagen_s_max"):
+            assert k in j["ranks"], k
+        assert j["ranks"]["ms_per_step_min"] <= j["ranks"]["ms_per_step_max"] <= j["ms_per_step"] * 1.01
