@@ -43,38 +43,43 @@ int blsbn254_g2_mul_batch(blsbn254_ctx* c, const uint8_t* g2, const uint8_t* sca
 static const size_t G2_SUM_GROUP = 16;
 static int g2_group_sums(blsbn254_ctx* c, const uint8_t* d_pks, size_t n, const uint64_t* goff, size_t n_groups, const int32_t** sum_ws, const uint8_t** sum_ok) {
   const size_t G = G2_SUM_GROUP;
+  // chunk descriptors of ALL levels first (host arithmetic on the offsets), uploaded in one copy: no synchronisation between levels
   std::vector<uint64_t> cur(goff, goff + n_groups + 1), nxt(n_groups + 1);
   for (size_t g = 0; g <= n_groups; ++g) cur[g] -= goff[0];
-  // ping-pong workspaces: the level-0 items (n) and the largest chunk array (<= n / G + n_groups)
-  const size_t m_max = n / G + n_groups + 1;
-  HIPCHK(c, c->gs_ws[0].reserve((n ? n : 1) * 54 * 4)); HIPCHK(c, c->gs_ok[0].reserve(n ? n : 1));
-  HIPCHK(c, c->gs_ws[1].reserve(m_max * 54 * 4)); HIPCHK(c, c->gs_ok[1].reserve(m_max));
-  HIPCHK(c, c->gs_ws[2].reserve(m_max * 54 * 4)); HIPCHK(c, c->gs_ok[2].reserve(m_max));
-  HIPCHK(c, c->gs_start.reserve(4 * m_max)); HIPCHK(c, c->gs_len.reserve(4 * m_max));
-  if (n) { LAUNCH(c, "g2_load", k_g2_load, n, d_pks, n, (int32_t*)c->gs_ws[0].p, (uint8_t*)c->gs_ok[0].p); }
-  int src = 0;
-  size_t items = n;
   std::vector<uint32_t> start, len;
+  std::vector<size_t> level_first, level_count;
   for (int level = 0; ; ++level) {
     if (level > 40) { c->last_error = "internal: group sums do not converge"; return BLSBN254_E_HIP; }
-    HIPCHK(c, hipStreamSynchronize(c->stream));                                 // the previous level's descriptor copies have been consumed
-    start.clear(); len.clear();
+    const size_t first = start.size();
     for (size_t g = 0; g < n_groups; ++g) {
       const uint64_t a = cur[g], b = cur[g + 1];
-      nxt[g] = start.size();
+      nxt[g] = start.size() - first;
       if (a == b) { start.push_back((uint32_t)a); len.push_back(0); }          // empty group: one empty chunk (identity, flag 0)
       for (uint64_t s = a; s < b; s += G) { start.push_back((uint32_t)s); len.push_back((uint32_t)(b - s < G ? b - s : G)); }
     }
-    nxt[n_groups] = start.size();
-    const size_t m = start.size();
-    if (m > m_max) { c->last_error = "internal: chunk count out of range"; return BLSBN254_E_HIP; }
-    const int dst = src == 1 ? 2 : 1;
-    HIPCHK(c, hipMemcpyAsync(c->gs_start.p, start.data(), 4 * m, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->gs_len.p, len.data(), 4 * m, hipMemcpyHostToDevice, c->stream));
-    LAUNCH(c, "g2_seg_sum", k_g2_seg_sum, m, (const int32_t*)c->gs_ws[src].p, items ? items : 1, (const uint8_t*)c->gs_ok[src].p,
-           (const uint32_t*)c->gs_start.p, (const uint32_t*)c->gs_len.p, m, (int32_t*)c->gs_ws[dst].p, m, (uint8_t*)c->gs_ok[dst].p);
-    src = dst; items = m; cur.swap(nxt);
+    const size_t m = start.size() - first;
+    nxt[n_groups] = m;
+    level_first.push_back(first); level_count.push_back(m);
+    cur.swap(nxt);
     if (m == n_groups) break;
+  }
+  const size_t total = start.size(), m_max = level_count[0];
+  // ping-pong workspaces: the level-0 items (n) and the largest chunk array (the first level's)
+  HIPCHK(c, c->gs_ws[0].reserve((n ? n : 1) * 54 * 4)); HIPCHK(c, c->gs_ok[0].reserve(n ? n : 1));
+  HIPCHK(c, c->gs_ws[1].reserve(m_max * 54 * 4)); HIPCHK(c, c->gs_ok[1].reserve(m_max));
+  HIPCHK(c, c->gs_ws[2].reserve(m_max * 54 * 4)); HIPCHK(c, c->gs_ok[2].reserve(m_max));
+  HIPCHK(c, c->gs_start.reserve(4 * total)); HIPCHK(c, c->gs_len.reserve(4 * total));
+  HIPCHK(c, hipMemcpyAsync(c->gs_start.p, start.data(), 4 * total, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->gs_len.p, len.data(), 4 * total, hipMemcpyHostToDevice, c->stream));
+  if (n) { LAUNCH(c, "g2_load", k_g2_load, n, d_pks, n, (int32_t*)c->gs_ws[0].p, (uint8_t*)c->gs_ok[0].p); }
+  int src = 0;
+  size_t items = n;
+  for (size_t lv = 0; lv < level_count.size(); ++lv) {
+    const size_t m = level_count[lv];
+    const int dst = src == 1 ? 2 : 1;
+    LAUNCH(c, "g2_seg_sum", k_g2_seg_sum, m, (const int32_t*)c->gs_ws[src].p, items ? items : 1, (const uint8_t*)c->gs_ok[src].p,
+           (const uint32_t*)c->gs_start.p + level_first[lv], (const uint32_t*)c->gs_len.p + level_first[lv], m, (int32_t*)c->gs_ws[dst].p, m, (uint8_t*)c->gs_ok[dst].p);
+    src = dst; items = m;
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));                                   // `start` / `len` go out of scope
   *sum_ws = (const int32_t*)c->gs_ws[src].p; *sum_ok = (const uint8_t*)c->gs_ok[src].p;
