@@ -54,6 +54,7 @@ int blsbn254_ctx_create(int device, blsbn254_ctx** out) {
   c->lanes_per_round = (size_t)prop.multiProcessorCount * 256;
   if (const char* e = std::getenv("BLSBN254_RLC_KEY_ROUND")) c->rlc_key_round = std::atoi(e) != 0;
   if (const char* e = std::getenv("BLSBN254_WIDE_FE")) c->wide_fe = std::atoi(e) != 0;
+  if (const char* e = std::getenv("BLSBN254_ASYNC_VERIFY")) c->async_verify = std::atoi(e) != 0;
   if (const char* e = std::getenv("BLSBN254_QUAD_PREP")) c->quad_prep = std::atoi(e) != 0;
   if (const char* e = std::getenv("BLSBN254_SPLIT_EASY")) c->split_easy = std::atoi(e) != 0;
   c->tri_max = c->lanes_per_round / 4;        // four lanes per tuple: one round of waves
@@ -68,6 +69,9 @@ void blsbn254_ctx_destroy(blsbn254_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
+  for (auto& pv : c->pend) if (pv.ev) (void)hipEventDestroy(pv.ev);       // pending checks are dropped: the caller did not ask for their results
+  if (c->pend_host) (void)hipHostFree(c->pend_host);
+  c->pend_dev.release();
   for (auto& kv : c->prof) for (auto& pr : kv.second.pending) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
   DevBuf* bufs[] = {&c->in_a, &c->in_b, &c->in_c, &c->in_off, &c->dst, &c->h_ws, &c->f_ws, &c->f_ws2, &c->flags, &c->sub_ok, &c->status, &c->status_all, &c->bitmap, &c->out, &c->scalars, &c->misc};
   for (DevBuf* b : bufs) b->release();
@@ -94,7 +98,12 @@ void blsbn254_ctx_destroy(blsbn254_ctx* c) {
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
-int blsbn254_ctx_synchronize(blsbn254_ctx* c) { if (!c) return BLSBN254_E_ARG; HIPCHK(c, hipStreamSynchronize(c->stream)); return 0; }
+int blsbn254_ctx_synchronize(blsbn254_ctx* c) {
+  if (!c) return BLSBN254_E_ARG;
+  ENTER(c);                                           // settles the asynchronously enqueued verify calls (re-running one whose assumption failed)
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return 0;
+}
 void* blsbn254_ctx_stream(blsbn254_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int blsbn254_profile_enable(blsbn254_ctx* c, int on) { if (!c) return BLSBN254_E_ARG; c->profiling = on != 0; return 0; }
@@ -131,7 +140,7 @@ struct EventPair {
 };
 int blsbn254_valu_probe(blsbn254_ctx* c, double out[6]) {
   if (!c || !out) return BLSBN254_E_ARG;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   hipDeviceProp_t prop;
   HIPCHK(c, hipGetDeviceProperties(&prop, c->device));
   const int blocks = prop.multiProcessorCount * 4, iters = 1 << 16;
@@ -292,7 +301,7 @@ int decode_status_rc(blsbn254_ctx* c, const uint8_t* d_status, size_t n) {
 int blsbn254_pairing_batch_dev(blsbn254_ctx* c, const uint8_t* d_g1, const uint8_t* d_g2, size_t n, uint8_t* d_gt, uint8_t* d_status) {
   if (!c || (n && (!d_g1 || !d_g2 || !d_gt))) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   HIPCHK(c, c->status_all.reserve(n));
   for (size_t lo = 0; lo < n; lo += c->chunk) {
     size_t m = n - lo < c->chunk ? n - lo : c->chunk;
@@ -308,7 +317,7 @@ int blsbn254_pairing_batch_dev(blsbn254_ctx* c, const uint8_t* d_g1, const uint8
 int blsbn254_pairing_batch(blsbn254_ctx* c, const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t* gt) {
   if (!c || (n && (!g1 || !g2 || !gt))) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   HIPCHK(c, c->in_a.reserve(64 * n)); HIPCHK(c, c->in_b.reserve(128 * n)); HIPCHK(c, c->out.reserve(384 * n));
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, g1, 64 * n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->in_b.p, g2, 128 * n, hipMemcpyHostToDevice, c->stream));
@@ -323,7 +332,7 @@ int blsbn254_pairing_batch(blsbn254_ctx* c, const uint8_t* g1, const uint8_t* g2
 int blsbn254_miller_loop_batch(blsbn254_ctx* c, const uint8_t* g1, const uint8_t* g2, size_t n, uint8_t* ml_out) {
   if (!c || (n && (!g1 || !g2 || !ml_out))) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   HIPCHK(c, c->in_a.reserve(64 * n)); HIPCHK(c, c->in_b.reserve(128 * n)); HIPCHK(c, c->out.reserve(384 * n));
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, g1, 64 * n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->in_b.p, g2, 128 * n, hipMemcpyHostToDevice, c->stream));
@@ -356,7 +365,7 @@ int blsbn254_multi_miller_loop(blsbn254_ctx* c, const uint8_t* g1, const uint8_t
   if (!c || !ml_out || (n && (!g1 || !g2))) return BLSBN254_E_ARG;
   if (n == 0) { std::memset(ml_out, 0, 384); ml_out[31] = 1; return 0; }       // empty product = Fp12::ONE
   CHECK_LANES(c, n);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   HIPCHK(c, c->in_a.reserve(64 * n)); HIPCHK(c, c->in_b.reserve(128 * n)); HIPCHK(c, c->out.reserve(384));
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, g1, 64 * n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->in_b.p, g2, 128 * n, hipMemcpyHostToDevice, c->stream));
@@ -375,7 +384,7 @@ int blsbn254_multi_miller_loop(blsbn254_ctx* c, const uint8_t* g1, const uint8_t
 int blsbn254_final_exponentiation(blsbn254_ctx* c, const uint8_t* ml, size_t n, uint8_t* gt) {
   if (!c || (n && (!ml || !gt))) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   HIPCHK(c, c->in_a.reserve(384 * n)); HIPCHK(c, c->out.reserve(384 * n));
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, ml, 384 * n, hipMemcpyHostToDevice, c->stream));
   for (size_t lo = 0; lo < n; lo += c->chunk) {
@@ -411,7 +420,7 @@ int stage_msgs(blsbn254_ctx* c, const uint8_t* msgs, const uint64_t* off, size_t
 static int h2c_common(blsbn254_ctx* c, const uint8_t* msgs, const uint64_t* off, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* out, int g2, int ro) {
   if (!c || (n && (!msgs && off && off[n] != off[0])) || !off || (n && !out) || (dst_len && !dst)) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
   if (rc) return rc;
   rc = stage_msgs(c, msgs, off, n);
@@ -433,7 +442,7 @@ int blsbn254_encode_to_g2_batch(blsbn254_ctx* c, const uint8_t* m, const uint64_
 static int check_common(blsbn254_ctx* c, const uint8_t* pts, size_t n, uint8_t* bm, int g2) {
   if (!c || (n && (!pts || !bm))) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   size_t sz = g2 ? 128 : 64, nb = (n + 7) / 8;
   HIPCHK(c, c->in_a.reserve(sz * n)); HIPCHK(c, c->bitmap.reserve(nb + 8));
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, pts, sz * n, hipMemcpyHostToDevice, c->stream));

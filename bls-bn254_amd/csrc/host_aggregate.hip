@@ -30,7 +30,7 @@ static int aggregate_partial_impl(blsbn254_ctx* c, const uint8_t* pks, const uin
   const size_t np = n + (extra_sig ? 1 : 0);                 // pairs in the loop
   if (np == 0) { std::memset(ml_out, 0, 384); ml_out[31] = 1; return 0; }
   CHECK_LANES(c, np);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   uint32_t dl = 0; int rc;
   if (n) {
     rc = stage_dst(c, dst, dst_len, &dl);                    // (a no-op when the tag is already resident)
@@ -62,7 +62,7 @@ static int aggregate_partial_impl(blsbn254_ctx* c, const uint8_t* pks, const uin
     if (u * 2 <= np && u <= PREP_MAX_KEYS) {
       HIPCHK(c, c->prep_table.reserve(64)); HIPCHK(c, c->prep_ok.reserve(u)); HIPCHK(c, c->prep_raw.reserve(u * PREP_RAW_LIMBS * 4));
       HIPCHK(c, fork_stream2(c));
-      LAUNCH_G2_PREPARE(c, LAUNCH2, (const uint8_t*)c->in_a.p, (const uint32_t*)c->kd_keys.p, u, (int32_t*)c->prep_raw.p, (uint8_t*)c->prep_ok.p);
+      LAUNCH_G2_PREPARE(c, LAUNCH2, (const uint8_t*)c->in_a.p, (const uint32_t*)c->kd_keys.p, u, (int32_t*)c->prep_raw.p, (uint8_t*)c->prep_ok.p, (const uint32_t*)nullptr);
       HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
       LAUNCH(c, "kd_propagate", k_kd_propagate, np, (const uint32_t*)c->kd_rep.p, (uint32_t)np, (uint32_t)u, (uint32_t*)c->kd_kid.p, (uint32_t*)nullptr);   // no sorting here: no histogram
       prepared = true;
@@ -112,7 +112,7 @@ int blsbn254_aggregate_partial_with_sig(blsbn254_ctx* c, const uint8_t* pks, con
 int blsbn254_aggregate_finish(blsbn254_ctx* c, const uint8_t* partials, size_t k, const uint8_t agg_sig[64], int* valid) {
   if (!c || !valid || (k && !partials) || (!k && !agg_sig)) return BLSBN254_E_ARG;
   *valid = 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   const bool with_sig = agg_sig != nullptr;                // NULL: a partial already carries ML(agg_sig, -G2gen)
   size_t m = k + (with_sig ? 1 : 0);                       // slot k holds ML(agg_sig, -G2gen)
   HIPCHK(c, c->in_a.reserve(384 * (k ? k : 1))); HIPCHK(c, c->in_b.reserve(64 + 128)); HIPCHK(c, c->f_ws.reserve(m * 108 * 4));
@@ -164,7 +164,7 @@ static int aggregate_verify_grouped(blsbn254_ctx* c, const uint8_t* pks, const u
                                     const uint8_t* dst, size_t dst_len, int* valid, bool* took) {
   Stream2Guard s2_guard(c);
   *took = false;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   uint32_t dl = 0;
   int rc = stage_dst(c, dst, dst_len, &dl);
   if (rc) return rc;
@@ -189,7 +189,7 @@ static int aggregate_verify_grouped(blsbn254_ctx* c, const uint8_t* pks, const u
   HIPCHK(c, hipStreamSynchronize(c->stream));                                   // last_key and the staged copies are consumed
   HIPCHK(c, c->prep_ok.reserve(np)); HIPCHK(c, c->prep_raw.reserve(np * PREP_RAW_LIMBS * 4));
   HIPCHK(c, fork_stream2(c));
-  LAUNCH_G2_PREPARE(c, LAUNCH2, (const uint8_t*)c->in_a.p, (const uint32_t*)c->kd_keys.p, np, (int32_t*)c->prep_raw.p, (uint8_t*)c->prep_ok.p);
+  LAUNCH_G2_PREPARE(c, LAUNCH2, (const uint8_t*)c->in_a.p, (const uint32_t*)c->kd_keys.p, np, (int32_t*)c->prep_raw.p, (uint8_t*)c->prep_ok.p, (const uint32_t*)nullptr);
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
   // key ids, key-sorted order
   HIPCHK(c, c->h_ws.reserve(n * 27 * 4)); HIPCHK(c, c->kd_cursor.reserve(4 * (u + 1))); HIPCHK(c, c->kd_perm.reserve(4 * n));
@@ -287,7 +287,7 @@ int g1_sum_to_bytes(blsbn254_ctx* c, size_t n, uint8_t out[64]) {
 int blsbn254_aggregate_sigs(blsbn254_ctx* c, const uint8_t* sigs, size_t n, uint8_t out[64]) {
   if (!c || !out || (n && !sigs)) return BLSBN254_E_ARG;
   if (n == 0) { std::memset(out, 0, 64); out[63] = 1; return 0; }            // empty sum = identity (0, 1)
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   HIPCHK(c, c->in_a.reserve(64 * n)); HIPCHK(c, c->h_ws.reserve(n * 27 * 4)); HIPCHK(c, c->status.reserve(n));
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, sigs, 64 * n, hipMemcpyHostToDevice, c->stream));
   LAUNCH(c, "g1_load", k_g1_load, n, (const uint8_t*)c->in_a.p, n, (int32_t*)c->h_ws.p, (uint8_t*)c->status.p);
@@ -302,7 +302,7 @@ int blsbn254_threshold_combine(blsbn254_ctx* c, const uint8_t* ids, const uint8_
   if (!c || !out_sig || (t && (!ids || !partial_sigs))) return BLSBN254_E_ARG;
   if (t == 0) { std::memset(out_sig, 0, 64); out_sig[63] = 1; return 0; }
   CHECK_LANES(c, t);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   size_t S = 1;
   while (S < 64 && S * S < t) ++S;                       // ~sqrt(t) slices: t x S lanes, critical path 2 (t / S + S) products
   const size_t J = (t + S - 1) / S;
@@ -354,7 +354,7 @@ int blsbn254_lagrange_at_zero(blsbn254_ctx* c, const uint8_t* ids, size_t t, uin
   if (!c || (t && (!ids || !out))) return BLSBN254_E_ARG;
   if (t == 0) return 0;
   CHECK_LANES(c, t);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   size_t S = 1;
   while (S < 64 && S * S < t) ++S;
   const size_t J = (t + S - 1) / S;

@@ -69,6 +69,18 @@ struct blsbn254_ctx {
   size_t tri_max = 16384;            // launches of wide_fe_max < n <= tri_max tuples run three lanes per tuple (k_tri.hip); BLSBN254_TRI_MAX, 0 = off
   bool tri_miller = true, tri_fe = true;   // BLSBN254_TRI_MILLER=0 / BLSBN254_TRI_FE=0: keep one of the two on the lane-per-tuple kernels (A/B runs)
   DevBuf tri_vals;                   // the named values of the tri hard part, TRI_VALUES x 108 x n limbs
+  // Asynchronous blsbn254_verify_batch_dev (host_verify.hip): calls whose pipeline was enqueued on the previous call's key count and
+  // whose check (res[1]) has not been read back yet, oldest first
+  struct PendingVerify {
+    bool active = false; const uint8_t *d_pks = nullptr, *d_msgs = nullptr, *d_sigs = nullptr; const uint64_t* d_off = nullptr;
+    size_t n = 0; uint8_t* d_bitmap = nullptr; uint8_t dst[256]; size_t dst_len = 0; hipEvent_t ev = nullptr;
+  } pend[4];
+  int pend_head = 0, pend_count = 0;
+  uint32_t* pend_host = nullptr;     // pinned, 4 slots x (u, ok)
+  DevBuf pend_dev;                   // the same on the device
+  size_t u_hint = 0;                 // distinct keys of the last chunk that took the prepared path (0: none yet)
+  bool async_verify = true;          // BLSBN254_ASYNC_VERIFY=0: every call reads the key count back before it enqueues the pipeline
+  uint64_t stat_async_chunks = 0, stat_async_reruns = 0;
   bool quad_prep = true;             // per-key preparation with four lanes per key while that fits one round of waves (BLSBN254_QUAD_PREP=0: off)
   bool split_easy = true;            // BLSBN254_SPLIT_EASY=0: the one-launch easy part at every size
   size_t wide_fe_max = 2048;         // ... used for launches of at most this many tuples (BLSBN254_WIDE_FE_MAX): two rounds of a wave per tuple
@@ -106,9 +118,9 @@ struct ProfScope {
 static const size_t TRI_VALUE_LIMBS = 20 * 108;      // tri.h TRI_VALUES x 108
 // G2Prepared::from for u keys (decode, on-curve, psi subgroup test, 88 line triples): four lanes per key (k_keyprep_quad.hip, half
 // the latency) while the 8 u lanes fit one round of waves, else one lane per key (k_keyprep.hip).  L = LAUNCH or LAUNCH2.
-#define LAUNCH_G2_PREPARE(ctx, L, pks, keys, u, raw, ok) do { \
-    if ((ctx)->quad_prep && 8 * (size_t)(u) <= (ctx)->lanes_per_round) { L(ctx, "g2_prepare", k_g2_prepare_quad, 2 * 256 * (size_t)nblocks(4 * (size_t)(u)), pks, keys, (uint32_t)(u), raw, ok); } \
-    else { L(ctx, "g2_prepare", k_g2_prepare, 2 * 256 * (size_t)nblocks(u), pks, keys, (uint32_t)(u), raw, ok); } } while (0)
+#define LAUNCH_G2_PREPARE(ctx, L, pks, keys, u, raw, ok, d_u) do { \
+    if ((ctx)->quad_prep && 8 * (size_t)(u) <= (ctx)->lanes_per_round) { L(ctx, "g2_prepare", k_g2_prepare_quad, 2 * 256 * (size_t)nblocks(4 * (size_t)(u)), pks, keys, (uint32_t)(u), raw, ok, d_u); } \
+    else { L(ctx, "g2_prepare", k_g2_prepare, 2 * 256 * (size_t)nblocks(u), pks, keys, (uint32_t)(u), raw, ok, d_u); } } while (0)
 
 // one workgroup of 64 lanes (one wave) per element: the wave-per-tuple kernels (wide.h)
 #define LAUNCH_WIDE(ctx, name, kernel, n, ...) do { ProfScope ps_(ctx, name); \
@@ -149,6 +161,12 @@ static inline hipError_t join_stream2(blsbn254_ctx* c) {
 
 #define BNH __attribute__((visibility("hidden")))
 extern "C" {
+// every entry point: select the device, then settle what the asynchronous verify path left open (read back its checks, re-run a
+// batch whose optimistic choice did not hold) -- results of earlier calls are final before this call touches the context
+BNH int resolve_pending(blsbn254_ctx* c, bool blocking);   // host_verify.hip
+BNH int blsbn254_internal_verify_batch_dev_sync(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
+                                                const uint8_t* d_sigs, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* d_bitmap);   // host_verify.hip
+#define ENTER(c) do { HIPCHK(c, hipSetDevice((c)->device)); if ((c)->pend_count) { int rc_ = resolve_pending(c, true); if (rc_) return rc_; } } while (0)
 extern BNH const uint8_t NEG_G2_BYTES[128];     // -G2gen = (x, p - y) of the generator fp2.rs:305-333, as bytes (host.hip)
 
 // The kernels address limb-major workspaces through a buffer descriptor with a 32-bit scalar byte offset
@@ -173,7 +191,7 @@ BNH int miller_to_ws(blsbn254_ctx* c, const uint8_t* d_g1, const uint8_t* d_g2, 
 BNH int decode_status_rc(blsbn254_ctx* c, const uint8_t* d_status, size_t n);   // host.hip
 BNH int product_tree(blsbn254_ctx* c, size_t n, const int32_t** result, size_t* rs);   // host.hip
 BNH int stage_msgs(blsbn254_ctx* c, const uint8_t* msgs, const uint64_t* off, size_t n);   // host.hip
-BNH int prepare_keys_async(blsbn254_ctx* c, const uint8_t* d_pks, const uint32_t* d_keys, size_t u, int32_t* table, uint8_t* key_ok);   // host_verify.hip
+BNH int prepare_keys_async(blsbn254_ctx* c, const uint8_t* d_pks, const uint32_t* d_keys, size_t u, int32_t* table, uint8_t* key_ok, const uint32_t* d_u);   // host_verify.hip
 BNH int verify_prepared_dev(blsbn254_ctx* c, const int32_t* table, const uint8_t* key_ok, size_t u, const uint32_t* d_kid, bool hist_done,
                                const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs, size_t n, uint32_t dl, uint8_t* d_bitmap, bool join);   // host_verify.hip
 BNH int dedup_keys(blsbn254_ctx* c, const uint8_t* d_pks, size_t n, size_t* u_out);   // host_verify.hip

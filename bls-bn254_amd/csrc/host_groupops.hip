@@ -9,7 +9,7 @@ extern "C" {
 static int mul_common(blsbn254_ctx* c, const uint8_t* pts, const uint8_t* scalars, size_t n, uint8_t* out, int g2) {
   if (!c || (n && (!pts || !scalars || !out))) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   const size_t sz = g2 ? 128 : 64;
   for (size_t lo = 0; lo < n; lo += c->chunk) {
     const size_t m = n - lo < c->chunk ? n - lo : c->chunk;
@@ -91,7 +91,7 @@ int blsbn254_aggregate_pks(blsbn254_ctx* c, const uint8_t* pks, size_t n, uint8_
   if (!c || !out || (n && !pks)) return BLSBN254_E_ARG;
   if (n == 0) { std::memset(out, 0, 128); out[127] = 1; return 0; }             // G2Affine::identity: x = 0, y = 1
   if (n > ((size_t)1 << 26)) { c->last_error = "more than 2^26 points in one sum"; return BLSBN254_E_ARG; }
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   HIPCHK(c, c->in_a.reserve(128 * n)); HIPCHK(c, c->out.reserve(128));
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * n, hipMemcpyHostToDevice, c->stream));
   const uint64_t goff[2] = {0, (uint64_t)n};
@@ -119,7 +119,7 @@ int blsbn254_fast_aggregate_verify_batch(blsbn254_ctx* c, const uint8_t* pks, co
   const size_t n_keys = (size_t)(key_off[n_groups] - key_off[0]);
   if (n_keys && !pks) return BLSBN254_E_ARG;
   if (n_keys > ((size_t)1 << 26) || n_groups > c->chunk) { c->last_error = "more than 2^26 keys or more groups than one launch chunk"; return BLSBN254_E_ARG; }
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
   if (rc) return rc;
   rc = stage_msgs(c, msgs, off, n_groups);

@@ -11,7 +11,7 @@ int blsbn254_field_op_batch(blsbn254_ctx* c, int op, const uint8_t* a, const uin
   const size_t w = field_op_width(op);
   if (!c || w == 0 || (n && (!a || !out || (field_op_binary(op) && !b)))) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   const bool bin = field_op_binary(op);
   HIPCHK(c, c->in_a.reserve(w * n)); HIPCHK(c, c->out.reserve(w * n)); HIPCHK(c, c->status.reserve(n));
   if (bin) HIPCHK(c, c->in_b.reserve(w * n));
@@ -32,7 +32,7 @@ int blsbn254_gt_mul_batch(blsbn254_ctx* c, const uint8_t* a, const uint8_t* b, s
 int blsbn254_gt_pow_batch(blsbn254_ctx* c, const uint8_t* gt, const uint8_t* scalars, size_t n, uint8_t* out) {
   if (!c || (n && (!gt || !scalars || !out))) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   HIPCHK(c, c->in_a.reserve(384 * n)); HIPCHK(c, c->in_b.reserve(32 * n)); HIPCHK(c, c->out.reserve(384 * n)); HIPCHK(c, c->status.reserve(n));
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, gt, 384 * n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->in_b.p, scalars, 32 * n, hipMemcpyHostToDevice, c->stream));
@@ -49,7 +49,7 @@ int blsbn254_gt_pow_batch(blsbn254_ctx* c, const uint8_t* gt, const uint8_t* sca
 static int codec_common(blsbn254_ctx* c, const uint8_t* in, size_t n, uint8_t* out, int g2, int mode) {
   if (!c || (n && (!in || !out))) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   size_t full = g2 ? 128 : 64, comp = full / 2;
   size_t isz = mode == 0 ? full : comp, osz = mode == 0 ? comp : full;
   HIPCHK(c, c->in_a.reserve(isz * n)); HIPCHK(c, c->out.reserve(osz * n)); HIPCHK(c, c->status.reserve(n));
@@ -73,7 +73,7 @@ int blsbn254_sign_batch(blsbn254_ctx* c, const uint8_t* sks, const uint8_t* msgs
                         const uint8_t* dst, size_t dst_len, uint8_t* sigs_out) {
   if (!c || !off || (n && (!sks || !sigs_out)) || (dst_len && !dst)) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
   if (rc) return rc;
   rc = stage_msgs(c, msgs, off, n);
@@ -93,7 +93,7 @@ int blsbn254_sign_batch(blsbn254_ctx* c, const uint8_t* sks, const uint8_t* msgs
 int blsbn254_sk_to_pk_batch(blsbn254_ctx* c, const uint8_t* sks, size_t n, uint8_t* pks_out) {
   if (!c || (n && (!sks || !pks_out))) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   HIPCHK(c, c->in_a.reserve(32 * n)); HIPCHK(c, c->out.reserve(128 * n)); HIPCHK(c, c->status.reserve(n));
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, sks, 32 * n, hipMemcpyHostToDevice, c->stream));
   LAUNCH(c, "sk_to_pk", k_sk_to_pk, n, (const uint8_t*)c->in_a.p, n, (uint8_t*)c->out.p, (uint8_t*)c->status.p);
@@ -111,7 +111,7 @@ int blsbn254_keygen_batch(blsbn254_ctx* c, const uint8_t* ikm, size_t ikm_len, s
                           uint8_t* sks_out) {
   if (!c || ikm_len < 32 || (n && (!ikm || !sks_out)) || (key_info_len && !key_info)) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   HIPCHK(c, c->in_a.reserve(ikm_len * n)); HIPCHK(c, c->in_c.reserve(key_info_len + 1));
   HIPCHK(c, c->out.reserve(32 * n)); HIPCHK(c, c->status.reserve(n));
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, ikm, ikm_len * n, hipMemcpyHostToDevice, c->stream));
@@ -131,7 +131,7 @@ int blsbn254_hash_to_scalar_batch(blsbn254_ctx* c, const uint8_t* msgs, const ui
                                   uint8_t* out) {
   if (!c || !off || (n && (!msgs && off[n] != off[0])) || (n && !out) || (dst_len && !dst)) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
   if (rc) return rc;
   rc = stage_msgs(c, msgs, off, n);
@@ -146,7 +146,7 @@ int blsbn254_hash_to_scalar_batch(blsbn254_ctx* c, const uint8_t* msgs, const ui
 int blsbn254_pop_prove_batch(blsbn254_ctx* c, const uint8_t* sks, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* proofs_out) {
   if (!c || (n && (!sks || !proofs_out)) || (dst_len && !dst)) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
   if (rc) return rc;
   HIPCHK(c, c->in_a.reserve(32 * n)); HIPCHK(c, c->in_c.reserve(128 * n)); HIPCHK(c, c->in_off.reserve(8 * (n + 1)));
@@ -168,14 +168,14 @@ int blsbn254_pop_verify_batch(blsbn254_ctx* c, const uint8_t* pks, const uint8_t
                               uint8_t* bm) {
   if (!c || (n && (!pks || !proofs || !bm)) || (dst_len && !dst)) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   size_t nb = (n + 7) / 8;
   HIPCHK(c, c->in_a.reserve(128 * n)); HIPCHK(c, c->in_b.reserve(64 * n)); HIPCHK(c, c->in_off.reserve(8 * (n + 1)));
   HIPCHK(c, c->bitmap.reserve(nb + 8));
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->in_b.p, proofs, 64 * n, hipMemcpyHostToDevice, c->stream));
   LAUNCH(c, "iota_off", k_iota_off, n + 1, (uint64_t*)c->in_off.p, n, (uint64_t)128);
-  int rc = blsbn254_verify_batch_dev(c, (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_a.p, (const uint64_t*)c->in_off.p,
+  int rc = blsbn254_internal_verify_batch_dev_sync(c, (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_a.p, (const uint64_t*)c->in_off.p,
                                      (const uint8_t*)c->in_b.p, n, dst, dst_len, (uint8_t*)c->bitmap.p);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(bm, c->bitmap.p, nb, hipMemcpyDeviceToHost, c->stream));

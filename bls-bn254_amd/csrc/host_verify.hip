@@ -10,11 +10,12 @@ extern "C" {
 
 // G2Prepared::from for u keys on the second stream (after ev_fork), ev_join recorded behind it.
 // keys == nullptr: key k = pks[128 k]; else key k = the public key of tuple keys[k].
-int prepare_keys_async(blsbn254_ctx* c, const uint8_t* d_pks, const uint32_t* d_keys, size_t u, int32_t* table, uint8_t* key_ok) {
+// d_u (optional): the key count on the device when u is only a capacity (the asynchronous path)
+int prepare_keys_async(blsbn254_ctx* c, const uint8_t* d_pks, const uint32_t* d_keys, size_t u, int32_t* table, uint8_t* key_ok, const uint32_t* d_u) {
   HIPCHK(c, c->prep_raw.reserve(u * PREP_RAW_LIMBS * 4));
   HIPCHK(c, fork_stream2(c));
-  LAUNCH_G2_PREPARE(c, LAUNCH2, d_pks, d_keys, u, (int32_t*)c->prep_raw.p, key_ok);
-  LAUNCH2(c, "g2_expand", k_g2_expand, u * (size_t)BN_NEG_G2_LINES, (const int32_t*)c->prep_raw.p, (uint32_t)u, table);
+  LAUNCH_G2_PREPARE(c, LAUNCH2, d_pks, d_keys, u, (int32_t*)c->prep_raw.p, key_ok, d_u);
+  LAUNCH2(c, "g2_expand", k_g2_expand, u * (size_t)BN_NEG_G2_LINES, (const int32_t*)c->prep_raw.p, (uint32_t)u, table, d_u);
   HIPCHK(c, hipEventRecord(c->ev_join, c->stream2));
   return 0;
 }
@@ -58,8 +59,8 @@ int verify_prepared_dev(blsbn254_ctx* c, const int32_t* table, const uint8_t* ke
   LAUNCH(c, "pack_bitmap", k_pack_bitmap, n, (const uint8_t*)c->prep_valid.p, n, d_bitmap);
   return 0;
 }
-// De-duplicate the public keys of a chunk.  *u_out = number of distinct keys; kd_kid / kd_keys / kd_hist are filled.
-int dedup_keys(blsbn254_ctx* c, const uint8_t* d_pks, size_t n, size_t* u_out) {
+// De-duplicate the public keys of a chunk: kd_rep / kd_kid / kd_keys and the count (kd_cnt) are filled on the device.
+static int dedup_enqueue(blsbn254_ctx* c, const uint8_t* d_pks, size_t n) {
   size_t m = 1;
   while (m < 2 * n) m <<= 1;
   // n + 1 entries: aggregate_verify_grouped appends the key of the signature's pair (-G2gen) as entry u, and u can be n
@@ -69,6 +70,12 @@ int dedup_keys(blsbn254_ctx* c, const uint8_t* d_pks, size_t n, size_t* u_out) {
   HIPCHK(c, hipMemsetAsync(c->kd_cnt.p, 0, 4, c->stream));
   LAUNCH(c, "kd_insert", k_kd_insert, n, d_pks, (uint32_t)n, (uint32_t*)c->kd_slots.p, (uint32_t)(m - 1), c->kd_seed, (uint32_t*)c->kd_rep.p);
   LAUNCH(c, "kd_assign", k_kd_assign, n, (const uint32_t*)c->kd_rep.p, (uint32_t)n, (uint32_t*)c->kd_kid.p, (uint32_t*)c->kd_cnt.p, (uint32_t*)c->kd_keys.p);
+  return 0;
+}
+// ... and *u_out = the number of distinct keys, read back (one 4-byte copy and a stream synchronisation)
+int dedup_keys(blsbn254_ctx* c, const uint8_t* d_pks, size_t n, size_t* u_out) {
+  int rc = dedup_enqueue(c, d_pks, n);
+  if (rc) return rc;
   uint32_t u = 0;
   HIPCHK(c, hipMemcpyAsync(&u, c->kd_cnt.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -105,24 +112,107 @@ int verify_chunk_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msg
     if (rc) return rc;
     if ((u * 2 <= n || small) && u <= PREP_MAX_KEYS) {
       HIPCHK(c, c->prep_table.reserve(u * PREP_KEY_LIMBS * 4)); HIPCHK(c, c->prep_ok.reserve(u));
-      rc = prepare_keys_async(c, d_pks, (const uint32_t*)c->kd_keys.p, u, (int32_t*)c->prep_table.p, (uint8_t*)c->prep_ok.p);
+      rc = prepare_keys_async(c, d_pks, (const uint32_t*)c->kd_keys.p, u, (int32_t*)c->prep_table.p, (uint8_t*)c->prep_ok.p, nullptr);
       if (rc) return rc;
       HIPCHK(c, hipMemsetAsync(c->kd_hist.p, 0, 4 * u, c->stream));
       LAUNCH(c, "kd_propagate", k_kd_propagate, n, (const uint32_t*)c->kd_rep.p, (uint32_t)n, (uint32_t)u, (uint32_t*)c->kd_kid.p, (uint32_t*)c->kd_hist.p);
       ++c->stat_prepared_chunks;
+      c->u_hint = u ? u : 1;
       return verify_prepared_dev(c, (const int32_t*)c->prep_table.p, (const uint8_t*)c->prep_ok.p, u, (const uint32_t*)c->kd_kid.p, true,
                                  d_msgs, d_off, d_sigs, n, dl, d_bitmap, true);
     }
   }
+  c->u_hint = 0;                                      // keys did not repeat: the next call counts them first again
   return verify_exact_dev(c, d_pks, d_msgs, d_off, d_sigs, n, dl, d_bitmap);
 }
-int blsbn254_verify_batch_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
-                              const uint8_t* d_sigs, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* d_bitmap) {
+// ---- asynchronous variant: no read-back before the pipeline is enqueued.
+// A steady caller's batches repeat their key set: after a chunk has taken the prepared-key path, the NEXT chunk is enqueued on the
+// assumption that it does too, with tables reserved for twice the last key count -- de-duplication, a one-lane decision kernel
+// (key count <= capacity, and at most half of the keys distinct unless the chunk is small), the per-key preparation bounded by
+// the DEVICE-side count, the table-only pipeline -- and the call returns.  Count and decision come back through a pinned
+// buffer behind an event; they are read by the next entry point that touches the context (ENTER) or by
+// blsbn254_ctx_synchronize.  If the assumption did not hold (a new key set, more keys than reserved), that batch's bitmap is
+// not valid yet: it is re-run on the counting path right there, before the caller can see it -- key ids beyond the capacity were
+// clamped by k_kd_propagate, so the discarded run indexed nothing out of bounds.  The caller's device buffers must stay untouched
+// until blsbn254_ctx_synchronize returns, as the header has always required of the device entry points.
+static int verify_chunk_async(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off, const uint8_t* d_sigs, size_t n,
+                              uint32_t dl, const uint8_t* dst, size_t dst_len, uint8_t* d_bitmap, bool* took) {
+  *took = false;
+  const bool small = (c->wide_fe && n <= c->wide_fe_max) || (c->tri_miller && c->tri_fe && n <= c->tri_max);
+  if (!c->async_verify || !c->auto_prepare || c->u_hint == 0 || !(n >= 1024 || small) || dst_len > 255) return 0;
+  size_t cap = 2 * c->u_hint < 1024 ? 1024 : 2 * c->u_hint;
+  if (cap > PREP_MAX_KEYS) cap = PREP_MAX_KEYS;
+  if (cap > n) cap = n;
+  if (!small && cap > n / 2) cap = n / 2;
+  if (cap == 0) return 0;
+  if (c->pend_count == 4) { int rc = resolve_pending(c, true); if (rc) return rc; }
+  if (!c->pend_host) {
+    HIPCHK(c, hipHostMalloc((void**)&c->pend_host, 4 * 2 * sizeof(uint32_t), hipHostMallocDefault));
+    HIPCHK(c, c->pend_dev.reserve(4 * 2 * sizeof(uint32_t)));
+    for (auto& pv : c->pend) HIPCHK(c, hipEventCreateWithFlags(&pv.ev, hipEventDisableTiming));
+  }
+  Stream2Guard s2_guard(c);
+  const int slot = (c->pend_head + c->pend_count) & 3;
+  uint32_t* d_res = (uint32_t*)c->pend_dev.p + 2 * slot;
+  int rc = dedup_enqueue(c, d_pks, n);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_kd_decide, dim3(1), dim3(1), 0, c->stream, (const uint32_t*)c->kd_cnt.p, (uint32_t)n, (uint32_t)cap, small ? 1 : 0, d_res);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, c->prep_table.reserve(cap * PREP_KEY_LIMBS * 4)); HIPCHK(c, c->prep_ok.reserve(cap));
+  rc = prepare_keys_async(c, d_pks, (const uint32_t*)c->kd_keys.p, cap, (int32_t*)c->prep_table.p, (uint8_t*)c->prep_ok.p, d_res);
+  if (rc) return rc;
+  HIPCHK(c, hipMemsetAsync(c->kd_hist.p, 0, 4 * cap, c->stream));
+  LAUNCH(c, "kd_propagate", k_kd_propagate, n, (const uint32_t*)c->kd_rep.p, (uint32_t)n, (uint32_t)cap, (uint32_t*)c->kd_kid.p, (uint32_t*)c->kd_hist.p);
+  rc = verify_prepared_dev(c, (const int32_t*)c->prep_table.p, (const uint8_t*)c->prep_ok.p, cap, (const uint32_t*)c->kd_kid.p, true,
+                           d_msgs, d_off, d_sigs, n, dl, d_bitmap, true);
+  if (rc) return rc;
+  blsbn254_ctx::PendingVerify& pv = c->pend[slot];
+  HIPCHK(c, hipMemcpyAsync(c->pend_host + 2 * slot, d_res, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipEventRecord(pv.ev, c->stream));
+  pv.active = true; pv.d_pks = d_pks; pv.d_msgs = d_msgs; pv.d_off = d_off; pv.d_sigs = d_sigs; pv.n = n; pv.d_bitmap = d_bitmap;
+  pv.dst_len = dst_len;
+  if (dst_len) std::memcpy(pv.dst, dst, dst_len);
+  ++c->pend_count;
+  ++c->stat_async_chunks;
+  *took = true;
+  return 0;
+}
+// Read back the checks of the asynchronously enqueued chunks, oldest first (blocking: all of them; else only those whose event has
+// fired); a chunk whose optimistic choice did not hold is re-run on the counting path.
+int resolve_pending(blsbn254_ctx* c, bool blocking) {
+  while (c->pend_count) {
+    blsbn254_ctx::PendingVerify& pv = c->pend[c->pend_head];
+    if (!blocking && hipEventQuery(pv.ev) != hipSuccess) { (void)hipGetLastError(); break; }
+    HIPCHK(c, hipEventSynchronize(pv.ev));
+    const uint32_t u = c->pend_host[2 * c->pend_head], ok = c->pend_host[2 * c->pend_head + 1];
+    const blsbn254_ctx::PendingVerify done = pv;
+    pv.active = false;
+    c->pend_head = (c->pend_head + 1) & 3; --c->pend_count;
+    if (ok) { c->u_hint = u ? u : 1; ++c->stat_prepared_chunks; continue; }
+    ++c->stat_async_reruns;
+    c->u_hint = 0;
+    uint32_t dl; int rc = stage_dst(c, done.dst, done.dst_len, &dl);
+    if (rc) return rc;
+    rc = verify_chunk_dev(c, done.d_pks, done.d_msgs, done.d_off, done.d_sigs, done.n, dl, done.d_bitmap);
+    if (rc) return rc;
+  }
+  return 0;
+}
+static int verify_batch_dev_impl(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
+                                 const uint8_t* d_sigs, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* d_bitmap, bool allow_async) {
   if (!c || (n && (!d_pks || !d_off || !d_sigs || !d_bitmap)) || (dst_len && !dst)) return BLSBN254_E_ARG;
   if (n == 0) return 0;
   HIPCHK(c, hipSetDevice(c->device));
-  uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
+  int rc = resolve_pending(c, !allow_async);           // settle what has already come back (everything, for a caller that reads the result right away)
   if (rc) return rc;
+  uint32_t dl; rc = stage_dst(c, dst, dst_len, &dl);   // (a new tag waits for the kernels that still read the old one)
+  if (rc) return rc;
+  if (allow_async && n <= c->chunk) {
+    bool took = false;
+    rc = verify_chunk_async(c, d_pks, d_msgs, d_off, d_sigs, n, dl, dst, dst_len, d_bitmap, &took);
+    if (rc || took) return rc;
+  }
+  if (c->pend_count) { rc = resolve_pending(c, true); if (rc) return rc; }     // the counting path reads back: settle the queue first
   for (size_t lo = 0; lo < n; lo += c->chunk) {        // chunk starts are multiples of 8: bitmap bytes do not straddle
     size_t m = n - lo < c->chunk ? n - lo : c->chunk;
     rc = verify_chunk_dev(c, d_pks + 128 * lo, d_msgs, d_off + lo, d_sigs + 64 * lo, m, dl, d_bitmap + lo / 8);
@@ -130,12 +220,33 @@ int blsbn254_verify_batch_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8
   }
   return 0;
 }
+int blsbn254_verify_batch_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
+                              const uint8_t* d_sigs, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* d_bitmap) {
+  return verify_batch_dev_impl(c, d_pks, d_msgs, d_off, d_sigs, n, dst, dst_len, d_bitmap, true);
+}
+// for callers inside the library that consume the bitmap on the stream right behind the call (host-pointer entry points, the
+// multi-device handle): the counting path, nothing left pending
+int blsbn254_internal_verify_batch_dev_sync(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
+                                            const uint8_t* d_sigs, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* d_bitmap) {
+  return verify_batch_dev_impl(c, d_pks, d_msgs, d_off, d_sigs, n, dst, dst_len, d_bitmap, false);
+}
+int blsbn254_async_stats(blsbn254_ctx* c, uint64_t out[2]) {
+  if (!c || !out) return BLSBN254_E_ARG;
+  out[0] = c->stat_async_chunks; out[1] = c->stat_async_reruns;
+  return 0;
+}
+int blsbn254_set_async_verify(blsbn254_ctx* c, int on) {
+  if (!c) return BLSBN254_E_ARG;
+  ENTER(c);
+  c->async_verify = on != 0;
+  return 0;
+}
 // ---------------- G2Prepared: explicit API
 int blsbn254_g2_prepare_batch(blsbn254_ctx* c, const uint8_t* pks, size_t u, blsbn254_g2prepared** out) {
   if (!c || !out || (u && !pks)) return BLSBN254_E_ARG;
   *out = nullptr;
   if (u + 1 > PREP_MAX_KEYS) { c->last_error = "more than 65535 keys in one prepared table"; return BLSBN254_E_ARG; }
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   // owned until handed to the caller: every failure path below releases the three device buffers and the object
   struct Owner {
     blsbn254_g2prepared* p;
@@ -148,8 +259,8 @@ int blsbn254_g2_prepare_batch(blsbn254_ctx* c, const uint8_t* pks, size_t u, bls
   HIPCHK(c, p->table.reserve(u1 * PREP_KEY_LIMBS * 4)); HIPCHK(c, p->ok.reserve(u1)); HIPCHK(c, c->in_a.reserve(128 * u1)); HIPCHK(c, p->raw.reserve(u1 * PREP_RAW_LIMBS * 4));
   if (u) HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * u, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync((uint8_t*)c->in_a.p + 128 * u, NEG_G2_BYTES, 128, hipMemcpyHostToDevice, c->stream));
-  LAUNCH_G2_PREPARE(c, LAUNCH, (const uint8_t*)c->in_a.p, (const uint32_t*)nullptr, u1, (int32_t*)p->raw.p, (uint8_t*)p->ok.p);
-  LAUNCH(c, "g2_expand", k_g2_expand, u1 * (size_t)BN_NEG_G2_LINES, (const int32_t*)p->raw.p, (uint32_t)u1, (int32_t*)p->table.p);
+  LAUNCH_G2_PREPARE(c, LAUNCH, (const uint8_t*)c->in_a.p, (const uint32_t*)nullptr, u1, (int32_t*)p->raw.p, (uint8_t*)p->ok.p, (const uint32_t*)nullptr);
+  LAUNCH(c, "g2_expand", k_g2_expand, u1 * (size_t)BN_NEG_G2_LINES, (const int32_t*)p->raw.p, (uint32_t)u1, (int32_t*)p->table.p, (const uint32_t*)nullptr);
   hipError_t es = hipStreamSynchronize(c->stream);
   if (es != hipSuccess) { (void)hipDeviceSynchronize(); }       // nothing may still be writing the buffers the owner frees
   HIPCHK(c, es);
@@ -169,7 +280,7 @@ size_t blsbn254_g2prepared_count(const blsbn254_g2prepared* p) { return p ? p->u
 int blsbn254_g2prepared_valid(blsbn254_ctx* c, const blsbn254_g2prepared* p, uint8_t* ok_bitmap) {
   if (!c || !p || p->ctx != c || (p->u && !ok_bitmap)) return BLSBN254_E_ARG;
   if (!p->u) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   HIPCHK(c, c->bitmap.reserve((p->u + 7) / 8 + 8));
   LAUNCH(c, "pack_bitmap", k_pack_bitmap, p->u, (const uint8_t*)p->ok.p, p->u, (uint8_t*)c->bitmap.p);
   HIPCHK(c, hipMemcpyAsync(ok_bitmap, c->bitmap.p, (p->u + 7) / 8, hipMemcpyDeviceToHost, c->stream));
@@ -180,7 +291,7 @@ int blsbn254_verify_batch_prepared(blsbn254_ctx* c, const blsbn254_g2prepared* k
                                    const uint8_t* sigs, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* bm) {
   if (!c || !keys || keys->ctx != c || !off || (n && (!key_idx || !sigs || !bm)) || (dst_len && !dst)) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
   if (rc) return rc;
   rc = stage_msgs(c, msgs, off, n);
@@ -207,7 +318,7 @@ int blsbn254_multi_miller_loop_prepared(blsbn254_ctx* c, const blsbn254_g2prepar
   if (!c || !keys || keys->ctx != c || !ml_out || (n && (!key_idx || !g1))) return BLSBN254_E_ARG;
   if (n == 0) { std::memset(ml_out, 0, 384); ml_out[31] = 1; return 0; }
   CHECK_LANES(c, n);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   const size_t n_lanes = (n + 1) / 2;
   HIPCHK(c, c->in_a.reserve(64 * n)); HIPCHK(c, c->kd_kid.reserve(4 * n)); HIPCHK(c, c->h_ws.reserve(n * 18 * 4)); HIPCHK(c, c->f_ws.reserve(n_lanes * 108 * 4));
   HIPCHK(c, c->status.reserve(n)); HIPCHK(c, c->flags.reserve(n)); HIPCHK(c, c->kd_hist.reserve(4 * (keys->u + 1))); HIPCHK(c, c->misc.reserve(64)); HIPCHK(c, c->out.reserve(384));
@@ -257,7 +368,7 @@ int blsbn254_aggregate_verify_prepared(blsbn254_ctx* c, const blsbn254_g2prepare
   if (n == 0) return 0;
   const size_t np = n + 1, n_lanes = (np + 1) / 2;
   CHECK_LANES(c, np);
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   uint32_t dl; int rc = stage_dst(c, dst, dst_len, &dl);
   if (rc) return rc;
   rc = stage_msgs(c, msgs, off, n);
@@ -311,14 +422,14 @@ int blsbn254_verify_batch(blsbn254_ctx* c, const uint8_t* pks, const uint8_t* ms
                           size_t n, const uint8_t* dst, size_t dst_len, uint8_t* bm) {
   if (!c || !off || (n && (!pks || !sigs || !bm)) || (dst_len && !dst)) return BLSBN254_E_ARG;
   if (n == 0) return 0;
-  HIPCHK(c, hipSetDevice(c->device));
+  ENTER(c);
   int rc = stage_msgs(c, msgs, off, n);
   if (rc) return rc;
   size_t nb = (n + 7) / 8;
   HIPCHK(c, c->in_a.reserve(128 * n)); HIPCHK(c, c->in_b.reserve(64 * n)); HIPCHK(c, c->bitmap.reserve(nb + 8));
   HIPCHK(c, hipMemcpyAsync(c->in_a.p, pks, 128 * n, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->in_b.p, sigs, 64 * n, hipMemcpyHostToDevice, c->stream));
-  rc = blsbn254_verify_batch_dev(c, (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p,
+  rc = blsbn254_internal_verify_batch_dev_sync(c, (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_c.p, (const uint64_t*)c->in_off.p,
                                  (const uint8_t*)c->in_b.p, n, dst, dst_len, (uint8_t*)c->bitmap.p);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(bm, c->bitmap.p, nb, hipMemcpyDeviceToHost, c->stream));

@@ -62,8 +62,11 @@ __global__ void __launch_bounds__(256) k_kd_propagate(const uint32_t* rep, uint3
     __syncthreads();
   }
   if (i < n) {
-    const uint32_t id = kid[rep[i]];
-    kid[i] = id;
+    // id < u always on the synchronous paths (u is the counted number of keys).  The asynchronous verify path passes a CAPACITY for
+    // u before the count is known on the host: ids beyond it are clamped, so that no later kernel indexes past the tables (that
+    // batch's results are then discarded and the batch re-run, host_verify.hip)
+    const uint32_t id0 = kid[rep[i]], id = id0 < u ? id0 : 0u;
+    kid[i] = id;                                       // counted under the clamped id as well: histogram, key ids and the sorted order stay consistent
     if (use_lds) atomicAdd(&lh[id], 1u);
     else if (hist) atomicAdd(&hist[id], 1u);
   }
@@ -123,11 +126,12 @@ __global__ void __launch_bounds__(256) k_kd_scatter(const uint32_t* kid, uint32_
 // length, and a launch over a few thousand keys is the latency of one lane: they run in DIFFERENT workgroups (the first
 // ceil(u / 256) workgroups compute lines, the next ceil(u / 256) validity), side by side instead of one after the other.
 // Launch with 2 * ceil(u / 256) workgroups of 256.
-BN_KERNEL k_g2_prepare(const uint8_t* pks, const uint32_t* keys, uint32_t u, int32_t* table, uint8_t* key_ok) {
+// d_u (optional): the number of keys as counted on the device; the launch is then sized for a capacity u and keys beyond *d_u are skipped
+BN_KERNEL k_g2_prepare(const uint8_t* pks, const uint32_t* keys, uint32_t u, int32_t* table, uint8_t* key_ok, const uint32_t* d_u) {
   const uint32_t nb = (u + 255u) / 256u;
   const bool check_role = blockIdx.x >= nb;
   const uint32_t k = (check_role ? blockIdx.x - nb : blockIdx.x) * blockDim.x + threadIdx.x;
-  if (k >= u) return;
+  if (k >= u || (d_u && k >= *d_u)) return;
   const uint8_t* b = pks + 128 * (size_t)(keys ? keys[k] : k);
   bool okd;
   G2A q = g2_decode(b, okd);
@@ -143,9 +147,9 @@ BN_KERNEL k_g2_prepare(const uint8_t* pks, const uint32_t* keys, uint32_t u, int
 }
 // The pair tables: lane (key k, step t) multiplies the key's line t with the fixed -G2gen line t (pairing.h line_pair_expand):
 // raw (u x 88 x 54 limbs) -> expanded (u x 88 x 162 limbs).  u x 88 lanes: the part of the preparation that is not sequential.
-BN_KERNEL k_g2_expand(const int32_t* raw, uint32_t u, int32_t* expanded) {
+BN_KERNEL k_g2_expand(const int32_t* raw, uint32_t u, int32_t* expanded, const uint32_t* d_u) {
   const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= u * (uint32_t)BN_NEG_G2_LINES) return;
+  if (e >= u * (uint32_t)BN_NEG_G2_LINES || (d_u && e >= *d_u * (uint32_t)BN_NEG_G2_LINES)) return;
   const uint32_t t = e % (uint32_t)BN_NEG_G2_LINES;
   const Line b = line_load_limbs(Ws{const_cast<int32_t*>(raw), 1, e * (uint32_t)(54 * 4), true});
   line_pair_expand(line_from_table(BN_NEG_G2_LINE_TABLE[t]), b, Ws{expanded, 1, e * (uint32_t)(162 * 4), true});
@@ -159,4 +163,13 @@ __global__ void k_prep_unsort(const uint8_t* is_one, const uint8_t* flags, const
 __global__ void __launch_bounds__(256) k_pack_bitmap(const uint8_t* valid, size_t n, uint8_t* bitmap) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   write_ballot(bitmap, n, i, i < n && valid[i] != 0);
+}
+
+// asynchronous verify path: res[0] = the counted number of distinct keys, res[1] = 1 when the optimistic choice holds (the keys fit
+// the capacity the tables were reserved for, and -- unless the chunk is small -- at most half of the tuples' keys are distinct)
+__global__ void k_kd_decide(const uint32_t* cnt, uint32_t n, uint32_t cap, int small, uint32_t* res) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const uint32_t u = *cnt;
+  res[0] = u;
+  res[1] = (u <= cap && (small || 2u * u <= n)) ? 1u : 0u;
 }

@@ -8,12 +8,12 @@
 #include "kernels.h"
 using namespace bn;
 
-BN_KERNEL k_g2_prepare_quad(const uint8_t* pks, const uint32_t* keys, uint32_t u, int32_t* table, uint8_t* key_ok) {
+BN_KERNEL k_g2_prepare_quad(const uint8_t* pks, const uint32_t* keys, uint32_t u, int32_t* table, uint8_t* key_ok, const uint32_t* d_u) {
   const uint32_t nb = (4u * u + 255u) / 256u;
   const bool check_role = blockIdx.x >= nb;
   const uint32_t lane = (check_role ? blockIdx.x - nb : blockIdx.x) * blockDim.x + threadIdx.x;
   const uint32_t k = lane >> 2, role = threadIdx.x & 3u;
-  if (k >= u) return;                              // whole quads leave together
+  if (k >= u || (d_u && k >= *d_u)) return;        // whole quads leave together
   const uint8_t* b = pks + 128 * (size_t)(keys ? keys[k] : k);
   bool okd;
   G2A q = g2_decode(b, okd);

@@ -111,9 +111,10 @@ __global__ void __launch_bounds__(256) k_kd_propagate(const uint32_t* rep, uint3
 __global__ void k_kd_hist(const uint32_t* kid, uint32_t n, uint32_t u, uint32_t* hist, int* bad);
 __global__ void __launch_bounds__(1024) k_scan_excl(const uint32_t* hist, uint32_t u, uint32_t* cursor);
 __global__ void __launch_bounds__(256) k_kd_scatter(const uint32_t* kid, uint32_t n, uint32_t u, uint32_t* cursor, uint32_t* perm);
-BN_KERNEL k_g2_prepare(const uint8_t* pks, const uint32_t* keys, uint32_t u, int32_t* table, uint8_t* key_ok);
-BN_KERNEL k_g2_prepare_quad(const uint8_t* pks, const uint32_t* keys, uint32_t u, int32_t* table, uint8_t* key_ok);
-BN_KERNEL k_g2_expand(const int32_t* raw, uint32_t u, int32_t* expanded);
+BN_KERNEL k_g2_prepare(const uint8_t* pks, const uint32_t* keys, uint32_t u, int32_t* table, uint8_t* key_ok, const uint32_t* d_u);
+BN_KERNEL k_g2_prepare_quad(const uint8_t* pks, const uint32_t* keys, uint32_t u, int32_t* table, uint8_t* key_ok, const uint32_t* d_u);
+BN_KERNEL k_g2_expand(const int32_t* raw, uint32_t u, int32_t* expanded, const uint32_t* d_u);
+__global__ void k_kd_decide(const uint32_t* cnt, uint32_t n, uint32_t cap, int small, uint32_t* res);
 __global__ void k_prep_unsort(const uint8_t* is_one, const uint8_t* flags, const uint32_t* perm, uint32_t n, uint8_t* valid);
 __global__ void __launch_bounds__(256) k_pack_bitmap(const uint8_t* valid, size_t n, uint8_t* bitmap);
 BN_KERNEL k_miller_prepared(const uint32_t* perm, const uint32_t* kid, const uint8_t* sigs, const int32_t* h_ws, size_t h_stride,

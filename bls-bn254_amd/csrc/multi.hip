@@ -73,6 +73,10 @@ struct blsbn254_multi {
 static size_t shard_lo(size_t n, size_t g, size_t G) { return g >= G ? n : ((n * g / G) & ~(size_t)7); }
 
 extern "C" {
+// library-internal (host_verify.hip; hidden visibility): blsbn254_verify_batch_dev on the counting path, nothing left pending
+__attribute__((visibility("hidden"))) int blsbn254_internal_verify_batch_dev_sync(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
+                                                                                  const uint8_t* d_sigs, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* d_bitmap);
+
 
 int blsbn254_multi_create(const int* devices, int ndev, blsbn254_multi** out) {
   if (!out || !devices || ndev < 1 || ndev > 64) return BLSBN254_E_ARG;
@@ -223,7 +227,8 @@ int blsbn254_verify_batch_multi_dev(blsbn254_multi* m, const uint8_t* const* d_p
   for (size_t g = 0; g < G; ++g) {
     if (!counts[g]) continue;
     th.emplace_back([=, &rcs]() {
-      rcs[g] = blsbn254_verify_batch_dev(m->ctx[g], d_pks[g], d_msgs[g], d_off[g], d_sigs[g], counts[g], dst, dst_len, (uint8_t*)m->local_bm[g]);
+      // the bitmap slice is consumed on the stream right behind (k_place_bitmap, the all-reduce): the variant that leaves nothing pending
+      rcs[g] = blsbn254_internal_verify_batch_dev_sync(m->ctx[g], d_pks[g], d_msgs[g], d_off[g], d_sigs[g], counts[g], dst, dst_len, (uint8_t*)m->local_bm[g]);
     });
   }
   for (std::thread& t : th) t.join();

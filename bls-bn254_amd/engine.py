@@ -192,6 +192,16 @@ class Engine:
                                                   ctypes.c_size_t(len(dst)), po))
         return o[:(n + 7) // 8].tobytes()
 
+    def set_async_verify(self, on):
+        """verify_batch_dev enqueues on the previous call's key count without reading the new one back first (default on)"""
+        self._chk(self._lib.blsbn254_set_async_verify(self._ctx, ctypes.c_int(1 if on else 0)))
+
+    def async_stats(self):
+        """(chunks enqueued on the assumption that the key set repeats, how many of them had to be re-run)"""
+        o = (ctypes.c_uint64 * 2)()
+        self._chk(self._lib.blsbn254_async_stats(self._ctx, o))
+        return int(o[0]), int(o[1])
+
     def set_auto_prepare(self, on):
         """verify_batch's automatic key de-duplication + per-key preparation (default on); off = exact per-tuple path."""
         self._chk(self._lib.blsbn254_set_auto_prepare(self._ctx, ctypes.c_int(1 if on else 0)))

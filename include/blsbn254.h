@@ -279,11 +279,21 @@ int blsbn254_g2_decompress_batch(blsbn254_ctx* ctx, const uint8_t* in /* n*64 */
 /* ---- device-resident variants (plumbing for callers that already hold the batch in HBM) ----- */
 /* All d_* pointers are device pointers on ctx's GPU.  Work is enqueued on ctx's stream and is
  * complete after blsbn254_ctx_synchronize().  d_valid_bitmap needs ceil(n/8) bytes.
- * blsbn254_verify_batch_dev is asynchronous except for ONE 4-byte read-back per chunk: the number of distinct public keys (it sizes
- * the per-key tables and chooses between the prepared-key and the exact per-tuple pipeline), i.e. the call returns once the key
- * de-duplication kernels of its last chunk have run -- everything behind them is still in flight.  Measured cost: the timed step
- * is 0.2 ms longer than the sum of its kernels.  Launch size picks the kernels: up to 2048 tuples one wave per tuple,
+ * blsbn254_verify_batch_dev does not wait for the device in steady state.  The number of distinct public keys sizes the per-key
+ * tables and chooses between the prepared-key and the exact per-tuple pipeline; the FIRST call on a context (and every call
+ * after one that took the exact path, and calls of more than one 4 Mi-tuple chunk) reads that 4-byte count back before it enqueues the
+ * pipeline.  After a call that took the prepared-key path, the next call is enqueued on the ASSUMPTION that its keys repeat
+ * likewise (tables reserved for twice the last count; the device-side count bounds the per-key work) and returns at once; count
+ * and a check of the assumption come back behind an event and are read by the next entry point on the context or by
+ * blsbn254_ctx_synchronize.  If the assumption failed (a new key set, more keys than reserved), that call is re-run on the
+ * counting path there -- before blsbn254_ctx_synchronize returns -- so the bitmap is final after blsbn254_ctx_synchronize as
+ * always (a caller that only synchronises the raw stream of blsbn254_ctx_stream must not rely on it).  Up to four calls stay in
+ * flight; the caller's device buffers must stay untouched until blsbn254_ctx_synchronize.  BLSBN254_ASYNC_VERIFY=0 or
+ * blsbn254_set_async_verify(ctx, 0) makes every call count first; blsbn254_async_stats: out[0] chunks enqueued on the
+ * assumption, out[1] of them re-run.  Launch size picks the kernels: up to 2048 tuples one wave per tuple,
  * up to 16384 three lanes per tuple, beyond one lane per tuple -- same values, same bitmap. */
+int blsbn254_set_async_verify(blsbn254_ctx* ctx, int on);
+int blsbn254_async_stats(blsbn254_ctx* ctx, uint64_t out[2] /* enqueued on the assumption, re-run */);
 int blsbn254_verify_batch_dev(blsbn254_ctx* ctx, const uint8_t* d_pks, const uint8_t* d_msgs, const uint64_t* d_off,
                               const uint8_t* d_sigs, size_t n, const uint8_t* dst, size_t dst_len, uint8_t* d_valid_bitmap);
 int blsbn254_pairing_batch_dev(blsbn254_ctx* ctx, const uint8_t* d_g1, const uint8_t* d_g2, size_t n, uint8_t* d_gt,

@@ -1334,3 +1334,75 @@ def test_aggregate_verify_mid_size_distinct_keys_on_quads(oracle, pyref, M, monk
         assert e_tri.aggregate_verify(pk, ms, IDENT1, dst) is False
     finally:
         e_tri.close(); e_ref.close()
+
+
+def _dev_batch(M, torch, pks, msgs, sigs):
+    data, off = M.engine.pack_messages(msgs)
+    dev = torch.device("cuda", 0)
+    t = [torch.frombuffer(bytearray(pks), dtype=torch.uint8).to(dev), torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev),
+         torch.from_numpy(off.astype(np.int64)).to(dev), torch.frombuffer(bytearray(sigs), dtype=torch.uint8).to(dev),
+         torch.full(((len(msgs) + 7) // 8,), 0x5a, dtype=torch.uint8, device=dev)]
+    torch.cuda.synchronize()
+    return t
+
+
+def test_verify_batch_dev_asynchronous_path(oracle, M):
+    """blsbn254_verify_batch_dev in steady state enqueues on the previous call's key count and returns; the check comes back at
+    blsbn254_ctx_synchronize.  Same bitmaps as the counting path: repeated calls, two calls in flight, a new domain-separation tag
+    between calls, and the cases where the assumption FAILS and the call is re-run -- more keys than reserved, a key set that no
+    longer repeats (exact path), then back to few keys."""
+    import torch
+    dst = M.DEFAULT_DST
+    e = M.Engine(0)
+    try:
+        def run(t, n, tag=dst):
+            e.verify_batch_dev(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), t[3].data_ptr(), n, t[4].data_ptr(), tag)
+        nA = 20000
+        pA, mA, sA, xA = synth.make_batch_gpu(e, oracle, nA, dst, pool=40, invalid_every=9, spot=10)
+        tA = _dev_batch(M, torch, pA, mA, sA); wantA = synth.bitmap_of(xA)
+        run(tA, nA); e.synchronize()
+        assert bytes(tA[4].cpu().numpy()) == wantA and e.async_stats() == (0, 0)          # the first call counts
+        tA[4].fill_(0x5a); run(tA, nA); e.synchronize()
+        assert bytes(tA[4].cpu().numpy()) == wantA and e.async_stats() == (1, 0)          # the second does not
+        # two calls in flight (different output buffers), then one synchronisation
+        tA2 = _dev_batch(M, torch, pA[:128 * 9000], mA[:9000], sA[:64 * 9000])
+        tA[4].fill_(0x5a)
+        run(tA, nA); run(tA2, 9000); e.synchronize()
+        assert bytes(tA[4].cpu().numpy()) == wantA and bytes(tA2[4].cpu().numpy()) == synth.bitmap_of(xA[:9000])
+        assert e.async_stats() == (3, 0)
+        # a different tag between two calls in flight: every signature is wrong under it
+        tA[4].fill_(0x5a); tA2[4].fill_(0x5a)
+        run(tA, nA); run(tA2, 9000, b"ANOTHER_TAG"); e.synchronize()
+        assert bytes(tA[4].cpu().numpy()) == wantA and not any(bytes(tA2[4].cpu().numpy()))
+        a0, r0 = e.async_stats()
+        # more keys than the tables were reserved for (40 keys -> capacity 1024; now 5000 keys): re-run, then the larger capacity holds
+        nC = 40000
+        pC, mC, sC, xC = synth.make_batch_gpu(e, oracle, nC, dst, pool=5000, invalid_every=11, spot=10)
+        tC = _dev_batch(M, torch, pC, mC, sC); wantC = synth.bitmap_of(xC)
+        run(tC, nC); e.synchronize()
+        assert bytes(tC[4].cpu().numpy()) == wantC and e.async_stats() == (a0 + 1, r0 + 1)
+        tC[4].fill_(0x5a); run(tC, nC); e.synchronize()                                   # (the re-run counted: this call counts too, the next is asynchronous)
+        tC[4].fill_(0x5a); run(tC, nC); e.synchronize()
+        assert bytes(tC[4].cpu().numpy()) == wantC and e.async_stats() == (a0 + 2, r0 + 1)
+        # a key set that does not repeat any more (beyond the mid-size limit: the exact path): the assumption fails, the re-run takes the exact path
+        nD = 17000
+        pD, mD, sD, xD = synth.make_batch_gpu(e, oracle, nD, dst, pool=nD, invalid_every=13, spot=10)
+        tD = _dev_batch(M, torch, pD, mD, sD); wantD = synth.bitmap_of(xD)
+        p0, x0 = e.path_stats()
+        run(tD, nD); e.synchronize()
+        assert bytes(tD[4].cpu().numpy()) == wantD and e.async_stats() == (a0 + 3, r0 + 2)
+        assert e.path_stats() == (p0, x0 + 1)
+        tD[4].fill_(0x5a); run(tD, nD); e.synchronize()                                   # after an exact chunk every call counts first
+        assert bytes(tD[4].cpu().numpy()) == wantD and e.async_stats() == (a0 + 3, r0 + 2)
+        # back to few keys; another entry point between a pending call and its synchronisation settles it
+        tA[4].fill_(0x5a); run(tA, nA); e.synchronize()
+        tA[4].fill_(0x5a); run(tA, nA)
+        assert e.g1_check_batch(oracle.g1_generator(), 1) == b"\x01"
+        assert bytes(tA[4].cpu().numpy()) == wantA
+        # switched off: every call counts
+        e.set_async_verify(False)
+        a1, r1 = e.async_stats()
+        tA[4].fill_(0x5a); run(tA, nA); e.synchronize()
+        assert bytes(tA[4].cpu().numpy()) == wantA and e.async_stats() == (a1, r1)
+    finally:
+        e.close()
