@@ -79,6 +79,8 @@ struct blsbn254_ctx {
   uint32_t* pend_host = nullptr;     // pinned, 4 slots x (u, ok)
   DevBuf pend_dev;                   // the same on the device
   size_t u_hint = 0;                 // distinct keys of the last chunk that took the prepared path (0: none yet)
+  size_t u_max_seen = 0;             // the largest key count a prepared chunk had on this context: the capacity never drops below it (a caller
+                                     // alternating between a small and a large key set would otherwise re-run every large batch)
   bool async_verify = true;          // BLSBN254_ASYNC_VERIFY=0: every call reads the key count back before it enqueues the pipeline
   uint64_t stat_async_chunks = 0, stat_async_reruns = 0;
   bool quad_prep = true;             // per-key preparation with four lanes per key while that fits one round of waves (BLSBN254_QUAD_PREP=0: off)

@@ -118,6 +118,7 @@ int verify_chunk_dev(blsbn254_ctx* c, const uint8_t* d_pks, const uint8_t* d_msg
       LAUNCH(c, "kd_propagate", k_kd_propagate, n, (const uint32_t*)c->kd_rep.p, (uint32_t)n, (uint32_t)u, (uint32_t*)c->kd_kid.p, (uint32_t*)c->kd_hist.p);
       ++c->stat_prepared_chunks;
       c->u_hint = u ? u : 1;
+      if (u > c->u_max_seen) c->u_max_seen = u;
       return verify_prepared_dev(c, (const int32_t*)c->prep_table.p, (const uint8_t*)c->prep_ok.p, u, (const uint32_t*)c->kd_kid.p, true,
                                  d_msgs, d_off, d_sigs, n, dl, d_bitmap, true);
     }
@@ -141,6 +142,7 @@ static int verify_chunk_async(blsbn254_ctx* c, const uint8_t* d_pks, const uint8
   const bool small = (c->wide_fe && n <= c->wide_fe_max) || (c->tri_miller && c->tri_fe && n <= c->tri_max);
   if (!c->async_verify || !c->auto_prepare || c->u_hint == 0 || !(n >= 1024 || small) || dst_len > 255) return 0;
   size_t cap = 2 * c->u_hint < 1024 ? 1024 : 2 * c->u_hint;
+  if (cap < c->u_max_seen) cap = c->u_max_seen;
   if (cap > PREP_MAX_KEYS) cap = PREP_MAX_KEYS;
   if (cap > n) cap = n;
   if (!small && cap > n / 2) cap = n / 2;
@@ -188,7 +190,7 @@ int resolve_pending(blsbn254_ctx* c, bool blocking) {
     const blsbn254_ctx::PendingVerify done = pv;
     pv.active = false;
     c->pend_head = (c->pend_head + 1) & 3; --c->pend_count;
-    if (ok) { c->u_hint = u ? u : 1; ++c->stat_prepared_chunks; continue; }
+    if (ok) { c->u_hint = u ? u : 1; if (u > c->u_max_seen) c->u_max_seen = u; ++c->stat_prepared_chunks; continue; }
     ++c->stat_async_reruns;
     c->u_hint = 0;
     uint32_t dl; int rc = stage_dst(c, done.dst, done.dst_len, &dl);

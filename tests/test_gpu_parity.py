@@ -1398,6 +1398,14 @@ def test_verify_batch_dev_asynchronous_path(oracle, M):
         tA[4].fill_(0x5a); run(tA, nA)
         assert e.g1_check_batch(oracle.g1_generator(), 1) == b"\x01"
         assert bytes(tA[4].cpu().numpy()) == wantA
+        # alternating between a small and a large key set: the capacity remembers the largest set seen, no call is re-run
+        a2, r2 = e.async_stats()
+        for _ in range(2):
+            tC[4].fill_(0x5a); run(tC, nC); e.synchronize()
+            assert bytes(tC[4].cpu().numpy()) == wantC
+            tA[4].fill_(0x5a); run(tA, nA); e.synchronize()
+            assert bytes(tA[4].cpu().numpy()) == wantA
+        assert e.async_stats() == (a2 + 4, r2)
         # switched off: every call counts
         e.set_async_verify(False)
         a1, r1 = e.async_stats()
