@@ -1,7 +1,7 @@
 """Latency of small calls: verify_batch / pairing_batch / aggregate_verify at n = 1 ... 8192 through the host-pointer C ABI
 (ctypes): with the wave-per-tuple (n <= 4096) and three-lanes-per-tuple (n <= 16384) kernels (default), with the former only
 (BLSBN254_TRI_MAX=0) and with neither (BLSBN254_WIDE_FE=0, BLSBN254_TRI_MAX=0).
-Usage: python scripts/bench_small.py  -> JSON on stdout"""
+Usage: python scripts/bench_small.py [sizes...]  -> JSON on stdout"""
 import json, os, sys, time
 sys.path.insert(0, os.getcwd())
 import blsbn254_loader; M = blsbn254_loader.load()
@@ -9,7 +9,7 @@ from oracle import oracle as O
 from tests import synth
 
 dst = M.DEFAULT_DST
-sizes = [1, 16, 256, 1024, 4096, 4100, 8192, 16384, 32768]
+sizes = [int(x) for x in sys.argv[1:]] or [1, 16, 256, 1024, 4096, 4100, 8192, 16384, 32768]
 out = {}
 e0 = M.Engine(0)
 nmax = max(sizes)

@@ -64,6 +64,9 @@ void hs_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) {
 }
 void hs_fp_sqr(const uint8_t* a, uint8_t* out) { bool o; Fp x = fp_from_be(a, o); fp_to_be(out, fp_sqr(x)); }
 void hs_fp_inv(const uint8_t* a, uint8_t* out) { bool o; Fp x = fp_from_be(a, o); fp_to_be(out, fp_inv(x)); }
+void hs_fp_inv_pow(const uint8_t* a, uint8_t* out) { bool o; Fp x = fp_from_be(a, o); fp_to_be(out, fp_inv_pow(x)); }
+// fp_inv (divstep recurrence) on a LAZY operand: x = a - b with limbs anywhere in the lazy range, as callers pass it
+void hs_fp_inv_lazy(const uint8_t* a, const uint8_t* b, uint8_t* out) { bool o; Fp x = fp_sub(fp_from_be(a, o), fp_from_be(b, o)); fp_to_be(out, fp_inv(x)); }
 // ((a+b)*(a-b) + 9a - b) exercising lazy ops
 void hs_fp_mix(const uint8_t* a, const uint8_t* b, uint8_t* out) {
   bool o1, o2;

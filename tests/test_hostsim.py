@@ -40,8 +40,16 @@ def test_fp_arithmetic(hs, pyref):
             hs.hs_fp_mul(b32(x), b32(y), out); assert int.from_bytes(out.raw, "big") == x * y % P
             hs.hs_fp_mix(b32(x), b32(y), out); assert int.from_bytes(out.raw, "big") == ((x + y) * (x - y) + 9 * x - y) % P
         hs.hs_fp_sqr(b32(x), out); assert int.from_bytes(out.raw, "big") == x * x % P
-    for x in (0, 1, rnd.randrange(P)):
-        hs.hs_fp_inv(b32(x), out); assert int.from_bytes(out.raw, "big") == pow(x, P - 2, P)      # inv0(0) = 0
+    # fp_inv = the divstep recurrence (21 batches of 29 steps), checked against Fermat's power (the reference's Fp::invert) and
+    # against the host-side copy of the power ladder: edge values, powers of two, long carry runs, random
+    cases = [0, 1, 2, 3, P - 1, P - 2, (P + 1) // 2, (P - 1) // 2, P // 3, 2 ** 253, 2 ** 253 + 1, 2 ** 200, 2 ** 29, 2 ** 29 - 1, 2 ** 58,
+             2 ** 232, 2 ** 232 - 1, (1 << 253) - 1] + [rnd.randrange(P) for _ in range(300)] + [rnd.randrange(1 << 64) for _ in range(20)]
+    for x in cases:
+        hs.hs_fp_inv(b32(x), out); assert int.from_bytes(out.raw, "big") == pow(x, P - 2, P), hex(x)      # inv0(0) = 0
+    for x in cases[:24]:
+        hs.hs_fp_inv_pow(b32(x), out); assert int.from_bytes(out.raw, "big") == pow(x, P - 2, P)
+        y = rnd.randrange(P)
+        hs.hs_fp_inv_lazy(b32(x), b32(y), out); assert int.from_bytes(out.raw, "big") == pow((x - y) % P, P - 2, P)
     assert hs.hs_fp_decode_ok(b32(P - 1)) == 1 and hs.hs_fp_decode_ok(b32(P)) == 0 and hs.hs_fp_decode_ok(b"\xff" * 32) == 0
     for okm in [os.urandom(48) for _ in range(10)] + [b"\xff" * 48, bytes(48)]:
         hs.hs_fp_from_okm(okm, out); assert int.from_bytes(out.raw, "big") == int.from_bytes(okm, "big") % P
