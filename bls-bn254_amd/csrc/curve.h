@@ -139,29 +139,36 @@ template <class F> BN_FUNC Proj<F> proj_mul_u64(const Proj<F>& p, uint64_t k) {
   }
   return acc;
 }
-// [x]P for the BN parameter x = 0x44e992b44a6909f1 by the addition chain also used for t^x in the final
-// exponentiation (pairing.h): 62 doublings + 17 additions instead of 64 + 28 for double-and-add; runs of
-// doublings are done in Jacobian coordinates.
-struct MulXOp { int8_t load, dbl, add, store; };
+// The BN parameter x = 0x44e992b44a6909f1 as a signed-digit chain over {1, 17, 35} -- negation is free in both places the chain is
+// used: a point's inverse is (x, -y), a cyclotomic element's inverse is its conjugate --
+//   _17 = 2^4 * 1 + 1,  _35 = 2 * _17 + 1,
+//   x = (((((((((((_35 << 6 - _35) << 7 + _17) << 2 + _35) << 4 - _35) << 4 - _35) << 9 + _35) << 4 + _35) << 6 + _17) << 5 + _35) << 5 - _17) << 5 + _17
+// = 62 doublings + 13 additions (binary: 62 + 27; the unsigned chain used until round 3: 62 + 17), found by exhaustive search
+// over dictionaries of up to five odd values below 64 with an optimal signed recoding for each (tools/x_chain_search.py).
+// One interpreter step: r <- slot[load] if load >= 0; r <- 2^sq r; r <- r + slot[mul] if mul >= 0; slot[store] <- r and
+// slot[cstore] <- -r if >= 0.  Slot 0 holds the input.  Shared by [x]P (below, quad.h) and t^x (pairing.h, tri.h, wide.h).
+struct ChainOp { int8_t load, sq, mul, store, cstore; };
+constexpr int BN_X_CHAIN_LEN = 13, BN_X_CHAIN_SLOTS = 5;
+#define BN_X_CHAIN {{-1, 4, 0, 1, 2}, {-1, 1, 0, 3, 4}, {-1, 6, 4, -1, -1}, {-1, 7, 1, -1, -1}, {-1, 2, 3, -1, -1}, {-1, 4, 4, -1, -1}, {-1, 4, 4, -1, -1}, \
+                    {-1, 9, 3, -1, -1}, {-1, 4, 3, -1, -1}, {-1, 6, 1, -1, -1}, {-1, 5, 3, -1, -1}, {-1, 5, 2, -1, -1}, {-1, 5, 1, -1, -1}}
+// [x]P by that chain; runs of doublings are done in Jacobian coordinates.
 template <class F> BN_FUNC Proj<F> proj_mul_bn_x(const Proj<F>& p) {
   BN_CTX;
-  const MulXOp prog[22] = {{-1, 1, -1, 1}, {-1, 1, -1, 2}, {-1, 1, -1, 3}, {-1, 1, 0, 4}, {-1, 0, 1, 5}, {-1, 0, 0, 6}, {3, 0, 4, 7},
-                           {5, 0, 6, 8}, {-1, 0, 1, 9}, {4, 1, -1, -1}, {-1, 6, 2, -1}, {-1, 0, 7, -1}, {-1, 7, 7, -1}, {-1, 8, 9, -1},
-                           {-1, 0, 1, -1}, {-1, 6, 4, -1}, {-1, 8, 9, -1}, {-1, 6, 9, -1}, {-1, 10, -1, -1}, {-1, 0, 8, -1}, {-1, 6, 9, -1},
-                           {-1, 0, 3, -1}};
-  Proj<F> slot[10];
+  const ChainOp prog[BN_X_CHAIN_LEN] = BN_X_CHAIN;
+  Proj<F> slot[BN_X_CHAIN_SLOTS];
   slot[0] = p;
   Proj<F> r = p;
-  for (int k = 0; k < 22; ++k) {
-    const MulXOp op = prog[k];
+  for (int k = 0; k < BN_X_CHAIN_LEN; ++k) {
+    const ChainOp op = prog[k];
     if (op.load >= 0) r = slot[op.load];
-    if (op.dbl >= 2) {                               // a run of doublings in Jacobian coordinates (2M + 5S each instead of 7M + 2S)
+    if (op.sq >= 2) {                                // a run of doublings in Jacobian coordinates (2M + 5S each instead of 7M + 2S)
       Proj<F> j = proj_to_jac(r);
-      for (int q = 0; q < op.dbl; ++q) j = jac_dbl(j);
+      for (int q = 0; q < op.sq; ++q) j = jac_dbl(j);
       r = proj_from_jac(j);
-    } else if (op.dbl == 1) r = proj_dbl(r);
-    if (op.add >= 0) r = proj_add(r, slot[op.add]);
+    } else if (op.sq == 1) r = proj_dbl(r);
+    if (op.mul >= 0) r = proj_add(r, slot[op.mul]);
     if (op.store >= 0) slot[op.store] = r;
+    if (op.cstore >= 0) slot[op.cstore] = proj_neg(r);
   }
   return r;
 }

@@ -1,7 +1,7 @@
 // k_fe_expx.hip -- t -> t^x in the cyclotomic subgroup (x = 0x44e992b44a6909f1) by the addition chain of
-// pairing.h (62 Granger-Scott squarings + 17 multiplications), fully inlined.  The running value r lives in
-// registers; the ten named powers of the chain are parked in a limb-major HBM workspace (10 x 432 B per
-// tuple, each re-read at most four times: ~10 KB per tuple against ~0.45 M VALU ops) so that r plus the
+// pairing.h (62 Granger-Scott squarings + 13 multiplications), fully inlined.  The running value r lives in
+// registers; the five named powers of the chain (t, t^17, t^35 and the conjugates of the last two) are parked in a limb-major
+// HBM workspace (432 B each per tuple, re-read at most five times: ~8 KB per tuple against ~0.4 M VALU ops) so that r plus the
 // temporaries of one product fit the 512 registers of a 1-wave-per-SIMD kernel.
 #include "lane_ops.h"
 #include "kernels.h"

@@ -374,29 +374,23 @@ BN_FUNC Fp12 cyclotomic_exp_x(const Fp12& f) {
 //   easy:  t  = f^((p^6-1)(p^2+1))
 //   hard:  t^(l0 + l1 p + l2 p^2 + l3 p^3), Fuentes-Castaneda et al. arrangement with three t -> t^x
 //          exponentiations (cyclotomic_exp_x) separated by the small steps h1, h2, h3.
-// f^x by the addition chain
-//   _10 = 2*1, _100 = 2*_10, _1000 = 2*_100, _10000 = 2*_1000, _10001 = 1 + _10000, _10011 = _10 + _10001,
-//   _10100 = 1 + _10011, _11001 = _1000 + _10001, _100010 = 2*_10001, _100111 = _10011 + _10100, _101001 = _10 + _100111,
-//   i27 = (_100010 << 6 + _100 + _11001) << 7 + _11001,  i44 = (i27 << 8 + _101001 + _10) << 6 + _10001,
-//   i70 = ((i44 << 8 + _101001) << 6 + _101001) << 10,   x = (_100111 + i70) << 6 + _101001 + _1000
-// = 62 cyclotomic squarings + 17 multiplications (binary: 27).  Run as a small uniform interpreter (one
-// inlined squaring and one inlined multiply-by-memory-operand in the loop body): the ten named powers
-// live in `slots` (limb-major memory, 10 x 108 limbs per lane) and are read back one Fp6 half at a time.
-struct ExpxOp { int8_t load, sq, mul, store; };
+// f^x by the signed chain BN_X_CHAIN (curve.h) = 62 cyclotomic squarings + 13 multiplications (binary: 27): f^-17 and f^-35 are
+// the conjugates of f^17 and f^35.  Run as a small uniform interpreter (one inlined squaring and one inlined
+// multiply-by-memory-operand in the loop body): the five named powers live in `slots` (limb-major memory, 10 x 108 limbs per
+// lane reserved) and are read back one Fp6 half at a time.
 BN_FUNC Fp12 cyclotomic_exp_x_chain(const Fp12& f, const Ws& slots, const Ws* park = nullptr) {
-  const ExpxOp prog[22] = {{-1, 1, -1, 1}, {-1, 1, -1, 2}, {-1, 1, -1, 3}, {-1, 1, 0, 4}, {-1, 0, 1, 5}, {-1, 0, 0, 6}, {3, 0, 4, 7},
-                           {5, 0, 6, 8}, {-1, 0, 1, 9}, {4, 1, -1, -1}, {-1, 6, 2, -1}, {-1, 0, 7, -1}, {-1, 7, 7, -1}, {-1, 8, 9, -1},
-                           {-1, 0, 1, -1}, {-1, 6, 4, -1}, {-1, 8, 9, -1}, {-1, 6, 9, -1}, {-1, 10, -1, -1}, {-1, 0, 8, -1}, {-1, 6, 9, -1},
-                           {-1, 0, 3, -1}};
+  const ChainOp prog[BN_X_CHAIN_LEN] = BN_X_CHAIN;
   fp12_store_mem(slots, f);
   BN_MEM_FENCE;
   Fp12 r = f;
-  for (int k = 0; k < 22; ++k) {
-    const ExpxOp op = prog[k];
+  for (int k = 0; k < BN_X_CHAIN_LEN; ++k) {
+    const ChainOp op = prog[k];
     if (op.load >= 0) r = fp12_load_mem(ws_at(slots, 108 * op.load));
     for (int q = 0; q < op.sq; ++q) r = fp12_cyclotomic_sqr(r);
     if (op.mul >= 0) r = fp12_mul_mem(r, ws_at(slots, 108 * op.mul), park);
-    if (op.store >= 0) { fp12_store_mem(ws_at(slots, 108 * op.store), r); BN_MEM_FENCE; }
+    if (op.store >= 0) fp12_store_mem(ws_at(slots, 108 * op.store), r);
+    if (op.cstore >= 0) { fp6_store_mem(ws_at(slots, 108 * op.cstore), r.c0); fp6_store_mem(ws_at(slots, 108 * op.cstore + 54), fp6_norm(fp6_neg(r.c1))); }
+    if (op.store >= 0 || op.cstore >= 0) BN_MEM_FENCE;
   }
   return r;
 }

@@ -163,23 +163,21 @@ BN_FUNC G2P quad_proj_from_jac(const G2P& j, uint32_t role) {
 // [x]P for the BN parameter by the addition chain of proj_mul_bn_x (curve.h), runs of doublings in Jacobian coordinates
 BN_FUNC G2P quad_mul_bn_x(const G2P& p, uint32_t role) {
   BN_CTX;
-  const MulXOp prog[22] = {{-1, 1, -1, 1}, {-1, 1, -1, 2}, {-1, 1, -1, 3}, {-1, 1, 0, 4}, {-1, 0, 1, 5}, {-1, 0, 0, 6}, {3, 0, 4, 7},
-                           {5, 0, 6, 8}, {-1, 0, 1, 9}, {4, 1, -1, -1}, {-1, 6, 2, -1}, {-1, 0, 7, -1}, {-1, 7, 7, -1}, {-1, 8, 9, -1},
-                           {-1, 0, 1, -1}, {-1, 6, 4, -1}, {-1, 8, 9, -1}, {-1, 6, 9, -1}, {-1, 10, -1, -1}, {-1, 0, 8, -1}, {-1, 6, 9, -1},
-                           {-1, 0, 3, -1}};
-  G2P slot[10];
+  const ChainOp prog[BN_X_CHAIN_LEN] = BN_X_CHAIN;
+  G2P slot[BN_X_CHAIN_SLOTS];
   slot[0] = p;
   G2P r = p;
-  for (int k = 0; k < 22; ++k) {
-    const MulXOp op = prog[k];
+  for (int k = 0; k < BN_X_CHAIN_LEN; ++k) {
+    const ChainOp op = prog[k];
     if (op.load >= 0) r = slot[op.load];
-    if (op.dbl >= 2) {
+    if (op.sq >= 2) {
       G2P j = quad_proj_to_jac(r, role);
-      for (int q = 0; q < op.dbl; ++q) j = quad_jac_dbl(j, role);
+      for (int q = 0; q < op.sq; ++q) j = quad_jac_dbl(j, role);
       r = quad_proj_from_jac(j, role);
-    } else if (op.dbl == 1) r = quad_proj_dbl(r, role);
-    if (op.add >= 0) r = quad_proj_add(r, slot[op.add], role);
+    } else if (op.sq == 1) r = quad_proj_dbl(r, role);
+    if (op.mul >= 0) r = quad_proj_add(r, slot[op.mul], role);
     if (op.store >= 0) slot[op.store] = r;
+    if (op.cstore >= 0) slot[op.cstore] = proj_neg(r);
   }
   return r;
 }

@@ -198,21 +198,20 @@ BN_FUNC Fp6 tri_miller_prepared(const Ws& cw, const Ws& ktab_in, uint32_t role) 
 enum : uint32_t { TV_T = 0, TV_A = 1, TV_B = 2, TV_C = 3, TV_B2 = 4, TV_D2 = 5, TV_X = 6, TV_E = 7, TV_D = 8, TV_TMP = 9, TV_SLOT0 = 10, TRI_VALUES = 20 };
 BN_INL Ws tri_val(const Ws& vals, uint32_t v) { return ws_at(vals, 108u * (size_t)v); }
 BN_FUNC Fp6 tri_exp_x(const Fp6& in, const Ws& vals, uint32_t role) {
-  const ExpxOp prog[22] = {{-1, 1, -1, 1}, {-1, 1, -1, 2}, {-1, 1, -1, 3}, {-1, 1, 0, 4}, {-1, 0, 1, 5}, {-1, 0, 0, 6}, {3, 0, 4, 7},
-                           {5, 0, 6, 8}, {-1, 0, 1, 9}, {4, 1, -1, -1}, {-1, 6, 2, -1}, {-1, 0, 7, -1}, {-1, 7, 7, -1}, {-1, 8, 9, -1},
-                           {-1, 0, 1, -1}, {-1, 6, 4, -1}, {-1, 8, 9, -1}, {-1, 6, 9, -1}, {-1, 10, -1, -1}, {-1, 0, 8, -1}, {-1, 6, 9, -1},
-                           {-1, 0, 3, -1}};
+  const ChainOp prog[BN_X_CHAIN_LEN] = BN_X_CHAIN;
   Ws vw = vals;
   tri_store(tri_val(vw, TV_SLOT0), in, role);
   BN_MEM_FENCE;
   Fp6 r = in;
-  for (int k = 0; k < 22; ++k) {
-    const ExpxOp op = prog[k];
+  for (int k = 0; k < BN_X_CHAIN_LEN; ++k) {
+    const ChainOp op = prog[k];
     BN_OPAQUE(vw);
     if (op.load >= 0) r = tri_load(tri_val(vw, TV_SLOT0 + (uint32_t)op.load), role);
     for (int q = 0; q < op.sq; ++q) r = tri_cyc_sqr(r, role);
     if (op.mul >= 0) r = tri_mul(r, tri_load(tri_val(vw, TV_SLOT0 + (uint32_t)op.mul), role), role);
-    if (op.store >= 0) { tri_store(tri_val(vw, TV_SLOT0 + (uint32_t)op.store), r, role); BN_MEM_FENCE; }
+    if (op.store >= 0) tri_store(tri_val(vw, TV_SLOT0 + (uint32_t)op.store), r, role);
+    if (op.cstore >= 0) tri_store(tri_val(vw, TV_SLOT0 + (uint32_t)op.cstore), tri_conj(r, role), role);
+    if (op.store >= 0 || op.cstore >= 0) BN_MEM_FENCE;
   }
   return r;
 }

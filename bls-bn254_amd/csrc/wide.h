@@ -236,20 +236,18 @@ BN_HD inline void wide_miller_1(const Wide& W, const G2A& q, const Ws& pt, const
   }
 #undef BN_WIDE_LINE_STEP
 }
-// out = in^x by the addition chain of cyclotomic_exp_x_chain (pairing.h): 62 squarings + 17 products; R is the accumulator
+// out = in^x by the signed chain of cyclotomic_exp_x_chain (pairing.h, BN_X_CHAIN): 62 squarings + 13 products; R is the accumulator
 BN_HD inline void wide_exp_x(const Wide& W, uint32_t out, uint32_t in) {
-  const ExpxOp prog[22] = {{-1, 1, -1, 1}, {-1, 1, -1, 2}, {-1, 1, -1, 3}, {-1, 1, 0, 4}, {-1, 0, 1, 5}, {-1, 0, 0, 6}, {3, 0, 4, 7},
-                           {5, 0, 6, 8}, {-1, 0, 1, 9}, {4, 1, -1, -1}, {-1, 6, 2, -1}, {-1, 0, 7, -1}, {-1, 7, 7, -1}, {-1, 8, 9, -1},
-                           {-1, 0, 1, -1}, {-1, 6, 4, -1}, {-1, 8, 9, -1}, {-1, 6, 9, -1}, {-1, 10, -1, -1}, {-1, 0, 8, -1}, {-1, 6, 9, -1},
-                           {-1, 0, 3, -1}};
+  const ChainOp prog[BN_X_CHAIN_LEN] = BN_X_CHAIN;
   wide_exec(W, WOP_COPY, WV_SLOT0, in, 0);
   wide_exec(W, WOP_COPY, WV_R, in, 0);
-  for (int k = 0; k < 22; ++k) {
-    const ExpxOp op = prog[k];
+  for (int k = 0; k < BN_X_CHAIN_LEN; ++k) {
+    const ChainOp op = prog[k];
     if (op.load >= 0) wide_exec(W, WOP_COPY, WV_R, WV_SLOT0 + (uint32_t)op.load, 0);
     if (op.sq > 0) wide_exec(W, WOP_SQR, WV_R, (uint32_t)op.sq, 0);
     if (op.mul >= 0) wide_exec(W, WOP_MUL, WV_R, WV_R, WV_SLOT0 + (uint32_t)op.mul);
     if (op.store >= 0) wide_exec(W, WOP_COPY, WV_SLOT0 + (uint32_t)op.store, WV_R, 0);
+    if (op.cstore >= 0) wide_exec(W, WOP_CONJ, WV_SLOT0 + (uint32_t)op.cstore, WV_R, 0);
   }
   wide_exec(W, WOP_COPY, out, WV_R, 0);
 }
