@@ -14,9 +14,9 @@ __global__ void __launch_bounds__(64) k_fe_hard_wide(const int32_t* t_ws, size_t
   __shared__ int32_t lds[WIDE_LDS_DWORDS];
   const size_t i = blockIdx.x;                       // uniform over the workgroup
   if (i >= n) return;
-  const Wide W{lds};
+  const Wide W(lds);
   const uint32_t lane = threadIdx.x;
-  if (lane < 6u) fp2_store_mem(wide_val(W, WV_T, lane), fp2_load_limbs(Ws{const_cast<int32_t*>(t_ws) + 18 * (size_t)lane * stride, stride, (uint32_t)i * 4u, true}));
+  if (lane < 6u) fp2_store_mem(wide_val(W, WV_T, lane), fp2_load_limbs(ws_at_lane(Ws{const_cast<int32_t*>(t_ws), stride, (uint32_t)i * 4u, true}, 18u * lane)));
   __syncthreads();
   wide_fe_hard(W);
   if (lane == 0u) {

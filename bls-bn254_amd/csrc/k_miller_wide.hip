@@ -15,19 +15,19 @@ __device__ inline void wide_store_result(const Wide& W, int32_t* f_ws, size_t f_
   if (lane < 6u) {
     const Fp2 one = lane == 0u ? fp2_one() : fp2_zero();
     const Fp2 v = fp2_select(live, fp2_load_mem(wide_val(W, WV_R, lane)), one);
-    fp2_store_limbs(Ws{f_ws + 18 * (size_t)lane * f_stride, f_stride, (uint32_t)col * 4u, true}, v);
+    fp2_store_limbs(ws_at_lane(ws_uniform(Ws{f_ws, f_stride, (uint32_t)col * 4u, true}), 18u * lane), v);      // lane-dependent offset, uniform buffer base
   }
 }
 }  // namespace
 
 __global__ void __launch_bounds__(64) k_miller_wide_prepared(const uint32_t* perm, const uint32_t* kid, const uint8_t* sigs, const int32_t* h_ws, size_t h_stride,
                                                              const int32_t* table, const uint8_t* key_ok, size_t n, int32_t* f_ws, uint8_t* flags) {
-  __shared__ int32_t lds[WIDE_PA_LIMBS + 108 * 2 + 81];            // product area, R, L, the nine coordinate values
+  __shared__ int32_t lds[WIDE_PA_LIMBS + 108 * 3 + 81];            // product area, R, L, L2, the nine coordinate values
   const size_t s = blockIdx.x;
   if (s >= n) return;
-  const Wide W{lds};
+  const Wide W(lds);
   const uint32_t i = perm[s], k = kid[i];
-  const Ws cw = {lds, 1, (WIDE_PA_LIMBS + 108u * 2u) * 4u, false};
+  const Ws cw = {lds, 1, (WIDE_PA_LIMBS + 108u * 3u) * 4u, false};
   if (threadIdx.x == 0) {                                          // prologue of k_miller_prepared, on one lane
     bool oks;
     G1A sig = g1_decode(sigs + 64 * (size_t)i, oks);
@@ -48,13 +48,13 @@ __global__ void __launch_bounds__(64) k_miller_wide_prepared(const uint32_t* per
 
 __global__ void __launch_bounds__(64) k_miller_wide_1p(const int32_t* h_ws, size_t h_stride, const uint32_t* kid, const int32_t* table, const uint8_t* key_ok, size_t n,
                                                        int32_t* f_ws, size_t f_stride, uint8_t* flags, const uint8_t* skip) {
-  __shared__ int32_t lds[WIDE_PA_LIMBS + 108 * 2 + 18];            // product area, R, L, (px, py)
+  __shared__ int32_t lds[WIDE_PA_LIMBS + 108 * 3 + 18];            // product area, R, L, L2, (px, py)
   const size_t i = blockIdx.x;
   if (i >= n) return;
-  const Wide W{lds};
+  const Wide W(lds);
   const uint32_t key = kid[i];
   const bool live = !(skip && (skip[i] & 2));
-  const Ws pt = {lds, 1, (WIDE_PA_LIMBS + 108u * 2u) * 4u, false};
+  const Ws pt = {lds, 1, (WIDE_PA_LIMBS + 108u * 3u) * 4u, false};
   if (threadIdx.x == 0) {
     const Ws hw = {const_cast<int32_t*>(h_ws), h_stride, (uint32_t)i * 4u, true};
     fp_store_mem(pt, fp_load_mem(hw)); fp_store_mem(ws_at(pt, 9), fp_load_mem(ws_at(hw, 9)));
@@ -68,10 +68,10 @@ __global__ void __launch_bounds__(64) k_miller_wide_1p(const int32_t* h_ws, size
 // k_miller_1 (pairing / miller_loop of arbitrary (G1, G2) pairs) with one wave per pair: lane 0 runs the point arithmetic of the
 // variable G2 point, the wave the Fp12 arithmetic.  status as lane_miller_1: bit 0 g1 decodes, bit 1 g2 decodes, bit 2 identity.
 __global__ void __launch_bounds__(64) k_miller_wide_1(const uint8_t* g1, const uint8_t* g2, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status) {
-  __shared__ int32_t lds[WIDE_PA_LIMBS + 108 * 2 + 18 + 54];       // product area, R, L, (px, py), the parked line triple
+  __shared__ int32_t lds[WIDE_PA_LIMBS + 108 * 3 + 18 + 54];       // product area, R, L, L2, (px, py), the parked line triple
   const size_t i = blockIdx.x;
   if (i >= n) return;
-  const Wide W{lds};
+  const Wide W(lds);
   bool ok1, ok2;
   G1A p = g1_decode(g1 + 64 * i, ok1);
   G2A q = g2_decode(g2 + 128 * i, ok2);
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(64) k_miller_wide_1(const uint8_t* g1, const u
   G1A gp; gp.x = fp_one(); gp.y = fp_norm(fp_add(fp_one(), fp_one()));
   p.x = fp_select(bad, gp.x, p.x); p.y = fp_select(bad, gp.y, p.y);
   q.x = fp2_norm(fp2_select(bad, fp2_const(bnc::G2_GEN_X), q.x)); q.y = fp2_norm(fp2_select(bad, fp2_const(bnc::G2_GEN_Y), q.y)); q.inf = false;
-  const Ws pt = {lds, 1, (WIDE_PA_LIMBS + 108u * 2u) * 4u, false}, lnw = {lds, 1, (WIDE_PA_LIMBS + 108u * 2u + 18u) * 4u, false};
+  const Ws pt = {lds, 1, (WIDE_PA_LIMBS + 108u * 3u) * 4u, false}, lnw = {lds, 1, (WIDE_PA_LIMBS + 108u * 3u + 18u) * 4u, false};
   if (threadIdx.x == 0) {
     fp_store_mem(pt, fp_norm(p.x)); fp_store_mem(ws_at(pt, 9), fp_norm(p.y));
     status[i] = (uint8_t)((ok1 ? 1 : 0) | (ok2 ? 2 : 0) | (ident ? 4 : 0));

@@ -147,6 +147,18 @@ BN_FUNC Fp12 fp12_mul(const Fp12& a, const Fp12& b) {     // fp12.rs:203-210 val
 struct Ws { int32_t* base; size_t stride; uint32_t lane4; bool buf; };
 BN_INL Ws ws_at(const Ws& w, size_t limbs) { return {w.base + limbs * w.stride, w.stride, w.lane4, w.buf}; }
 BN_INL int32_t* ws_addr(const Ws& w, int k) { return (int32_t*)((char*)(w.base + (size_t)k * w.stride) + w.lane4); }
+// The same reference with its base marked wave-uniform.  Buffer addressing keeps the base in scalar registers; a base that
+// reaches the load through the arguments of a REAL function (wide.h's noinline primitives) is not known to be uniform, and every
+// load would be wrapped in a serialising loop over the distinct bases of the wave.  Only for bases that ARE the same in every lane.
+BN_INL Ws ws_uniform(const Ws& w) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const uint64_t b = (uint64_t)w.base;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  return {(int32_t*)(((uint64_t)hi << 32) | lo), w.stride, w.lane4, w.buf};
+#else
+  return w;
+#endif
+}
 BN_INL int32_t ws_load(const Ws& w, int k) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (w.buf)

@@ -29,10 +29,23 @@ namespace bn {
 enum : uint32_t { WIDE_PA_LIMBS = 36 * 18, WIDE_VALUES = 20, WIDE_LDS_DWORDS = WIDE_PA_LIMBS + 108 * WIDE_VALUES };
 // value ids of the hard part
 enum : uint32_t { WV_R = 0, WV_T = 1, WV_A = 2, WV_B = 3, WV_C = 4, WV_B2 = 5, WV_D2 = 6, WV_X = 7, WV_E = 8, WV_D = 9, WV_TMP = 10, WV_SLOT0 = 10 };   // chain slots 10..19 (TMP shares slot 0's place outside a chain)
-struct Wide { int32_t* lds; };
+// The primitives below are REAL functions on the device (one instance each per kernel), so the region's base reaches them as an
+// argument: it is carried as an LDS-typed pointer, or every access would be a flat (generic address space) load or store
+// instead of ds_read / ds_write.  wide_local(W, w) re-bases a reference into the same LDS array (the kernels' coordinate and
+// line areas: Ws{lds, 1, byte offset, false}) the same way; on the host it is the reference itself.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) int32_t wide_lds_i32;
+struct Wide { wide_lds_i32* lds; __device__ explicit Wide(int32_t* p) : lds((wide_lds_i32*)p) {} };
+BN_INL int32_t* wide_base(const Wide& w) { return (int32_t*)w.lds; }
+BN_INL Ws wide_local(const Wide& w, const Ws& r) { return Ws{wide_base(w), 1, r.lane4, false}; }
+#else
+struct Wide { int32_t* lds; BN_HD explicit Wide(int32_t* p) : lds(p) {} };
+BN_INL int32_t* wide_base(const Wide& w) { return w.lds; }
+BN_INL Ws wide_local(const Wide&, const Ws& r) { return r; }
+#endif
 
-BN_INL Ws wide_val(const Wide& w, uint32_t v, uint32_t slot) { return Ws{w.lds, 1, (WIDE_PA_LIMBS + 108u * v + 18u * slot) * 4u, false}; }
-BN_INL Ws wide_pa(const Wide& w, uint32_t idx) { return Ws{w.lds, 1, 18u * idx * 4u, false}; }
+BN_INL Ws wide_val(const Wide& w, uint32_t v, uint32_t slot) { return Ws{wide_base(w), 1, (WIDE_PA_LIMBS + 108u * v + 18u * slot) * 4u, false}; }
+BN_INL Ws wide_pa(const Wide& w, uint32_t idx) { return Ws{wide_base(w), 1, 18u * idx * 4u, false}; }
 // tower slot of the coefficient of w^k (f = sum_k f_k w^k, w^2 = v, w^6 = xi)
 BN_INL uint32_t wide_slot_of_w(uint32_t k) { return (k & 1u) ? 3u + (k >> 1) : (k >> 1); }
 // tower slot of z_i in the Granger-Scott labelling (z0 = c0.c0, z4 = c0.c1, z3 = c0.c2, z2 = c1.c0, z1 = c1.c1, z5 = c1.c2)
@@ -44,15 +57,9 @@ BN_INL Fp2 wide_sum6(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d, con
   return {fp_lc3<1, 1, 1>(s.c0, e.c0, f.c0), fp_lc3<1, 1, 1>(s.c1, e.c1, f.c1)};
 }
 
-// dst = a * b.  Phase 1: lane (i, j) forms a_i b_j (coefficients of w^i, w^j).  Phase 2: lane k sums the products with
-// i + j = k and xi times those with i + j = k + 6.  dst may be a or b.
-BN_FUNC void wide_mul(const Wide& W, uint32_t dst, uint32_t a, uint32_t b) {
-  BN_WIDE_PHASE(lane,
-    if (lane < 36u) {
-      const uint32_t i = lane / 6u, j = lane - 6u * i;
-      const Fp2 x = fp2_load_mem(wide_val(W, a, wide_slot_of_w(i))), y = fp2_load_mem(wide_val(W, b, wide_slot_of_w(j)));
-      fp2_store_mem(wide_pa(W, lane), fp2_mul(x, y));
-    })
+// dst = a * b.  Phase 1: lane (i, j) forms a_i b_j (coefficients of w^i, w^j).  Phase 2 (wide_mul_sums): lane k sums the
+// products with i + j = k and xi times those with i + j = k + 6.  dst may be a or b.
+BN_FUNC void wide_mul_sums(const Wide& W, uint32_t dst) {
   BN_WIDE_PHASE(lane,
     if (lane < 6u) {
       const uint32_t k = lane;
@@ -66,6 +73,15 @@ BN_FUNC void wide_mul(const Wide& W, uint32_t dst, uint32_t a, uint32_t b) {
       fp2_store_mem(wide_val(W, dst, wide_slot_of_w(k)), fp2_add_mul_xi(sd, sw));
     })
 }
+BN_FUNC void wide_mul_products(const Wide& W, uint32_t a, uint32_t b) {
+  BN_WIDE_PHASE(lane,
+    if (lane < 36u) {
+      const uint32_t i = lane / 6u, j = lane - 6u * i;
+      const Fp2 x = fp2_load_mem(wide_val(W, a, wide_slot_of_w(i))), y = fp2_load_mem(wide_val(W, b, wide_slot_of_w(j)));
+      fp2_store_mem(wide_pa(W, lane), fp2_mul(x, y));
+    })
+}
+BN_FUNC void wide_mul(const Wide& W, uint32_t dst, uint32_t a, uint32_t b) { wide_mul_products(W, a, b); wide_mul_sums(W, dst); }
 // v = v^2 for v in the cyclotomic subgroup (same values as fp12_cyclotomic_sqr, tower.h).  Phase 1: lane (pair p, kind q)
 // squares a, b or a + b of the pair (z0, z1), (z2, z3), (z4, z5).  Phase 2: lane o forms r_o in the slot of z_o.
 BN_FUNC void wide_cyc_sqr(const Wide& W, uint32_t v) {
@@ -122,42 +138,67 @@ BN_FUNC void wide_frob(const Wide& W, uint32_t dst, uint32_t src) {
 // ---- Miller loops over prepared keys (no point arithmetic): per loop digit  R <- R^2, then R <- R * L  with the line value L
 // assembled by five lanes from the key's table and the tuple's coordinates.  L is stored as a full Fp12 value (zero slots
 // where the line has no coefficient) and multiplied in by the general wide_mul: at one wave per tuple the chain length counts,
-// not the 6 of 36 products that are spent on zeros.
-// One pair, raw line triple (54 limbs at `line`), affine point (px, py) at pt (LDS, 18 limbs): L = c0 py + c1 px w + c2 w^3 (ell, pairing.h)
-// (PARKED: the triple was written by fp2_store_mem -- a line just computed by lane 0 -- instead of read from a key's table)
-template <bool PARKED = false>
-BN_FUNC void wide_line_eval_1(const Wide& W, uint32_t dst, const Ws& line, const Ws& pt) {
+// not the 6 of 36 products that are spent on zeros.  One pair: L = c0 py + c1 px w + c2 w^3 (ell, pairing.h) from the raw triple;
+// two pairs: L = (T0 ysY + T1 Z) + T2 xsX v + (T3 xsZ + T4 X) v^2 + [(T5 ysX + T6 xsY) + (T7 ysZ + T8 Y) v] w from the pair table
+// entry T0..T8 of ell_pair_expanded (pairing.h) and the nine coordinate values X, Y, Z, xs X, ys Y, xs Z, ys Z, ys X, xs Y.
+// The product phase of dst = a * b (wide_mul's phase 1) with up to TWO line values evaluated by otherwise idle lanes in the SAME
+// instruction stream: an Fp2 product and a line coefficient are both a pair of double products,
+//   product lane (i, j):  { x0 y0 + (-x1) y1,  x0 y1 + x1 y0 }            line lane (q, s):  { TA0 sa + TB0 sb,  TA1 sa + TB1 sb }
+// so every lane first fetches ITS eight operands (the only divergent part: a few loads) and then all run the same two fp_dot2.
+// Lanes 0..35 form the products (skipped when `prod` is false: the two final lines have no squaring), lanes 36 + 6 q + s the
+// coefficient of tower slot s of line q, written to value WV_L + q.  Line operands:
+//   mode 0: pair table entry (162 limbs, T0..T8) at ln (+ 162 q), cw = the nine coordinate values (wide_line_eval_pair)
+//   mode 1: raw triple (54 limbs) at ln (+ 54 q), cw = (px, py)                                    (wide_line_eval_1<false>)
+//   mode 2: the triple parked in LDS by fp2_store_mem at ln, cw = (px, py); one line                (wide_line_eval_1<true>)
+// wide_mul_sums(dst) (wide_mul's phase 2) completes the product.
+enum : uint32_t { WV_L = 1, WV_L2 = 2 };                            // the line values (the Miller loops do not use WV_T, WV_A)
+BN_FUNC void wide_mul_products_lines(const Wide& W, bool prod, uint32_t a, uint32_t b, uint32_t nlines, const Ws& ln_in, const Ws& cw_in, int mode) {
+  // This is a real function: what the kernel knows about its references is restated here -- the key's table is buffer-addressed,
+  // dense (stride 1) and one base for the whole wave; the coordinates and a parked line live in the wave's LDS region.
+  const Ws tab = {ws_uniform(ln_in).base, 1, ln_in.lane4, true}, lnl = wide_local(W, ln_in), cw = wide_local(W, cw_in);
   BN_WIDE_PHASE(lane,
-    if (lane < 6u) {
-      const uint32_t s = lane;
-      const bool used = s == 0u || s == 3u || s == 4u;              // tower slots of w^0, w^1, w^3
-      const Ws lw = ws_at(line, s == 3u ? 18u : s == 4u ? 36u : 0u);
-      const Fp2 coef = PARKED ? fp2_load_mem(lw) : fp2_load_limbs(lw);
-      const Fp px = fp_load_mem(pt), py = fp_load_mem(ws_at(pt, 9));
-      const Fp sc = fp_select(s == 0u, py, fp_select(s == 3u, px, fp_one()));
-      fp2_store_mem(wide_val(W, dst, s), fp2_select(used, fp2_mul_fp(coef, sc), fp2_zero()));
+    const bool is_prod = prod && lane < 36u, is_line = lane >= 36u && lane < 36u + 6u * nlines;
+    if (is_prod || is_line) {
+      Fp a0, b0, c0, d0, a1, b1, c1, d1;
+      bool used = true;
+      Ws out;
+      if (is_prod) {
+        const uint32_t i = lane / 6u, j = lane - 6u * i;
+        const Fp2 x = fp2_load_mem(wide_val(W, a, wide_slot_of_w(i))), y = fp2_load_mem(wide_val(W, b, wide_slot_of_w(j)));
+        a0 = x.c0; b0 = y.c0; c0 = fp_neg(x.c1); d0 = y.c1; a1 = x.c0; b1 = y.c1; c1 = x.c1; d1 = y.c0;
+        out = wide_pa(W, lane);
+      } else {
+        const uint32_t q = (lane - 36u) / 6u, sl = lane - 36u - 6u * q;      // line, tower slot
+        Fp2 ta, tb;
+        Fp sa, sb;
+        if (mode == 0) {
+          const uint32_t ia = sl == 0u ? 0u : sl == 1u ? 2u : sl == 2u ? 3u : sl == 3u ? 5u : 7u, ib = sl == 0u ? 1u : sl == 1u ? 2u : sl == 2u ? 4u : sl == 3u ? 6u : 8u;
+          const uint32_t ca = sl == 0u ? 4u : sl == 1u ? 3u : sl == 2u ? 5u : sl == 3u ? 7u : 6u, cb = sl == 0u ? 2u : sl == 2u ? 0u : sl == 3u ? 8u : 1u;
+          ta = fp2_load_limbs(ws_at_lane(tab, 162u * q + 18u * ia)); tb = fp2_load_limbs(ws_at_lane(tab, 162u * q + 18u * ib));
+          sa = fp_load_mem(ws_at_lane(cw, 9u * ca));
+          sb = fp_select(sl == 1u, fp_zero(), fp_load_mem(ws_at_lane(cw, 9u * cb)));      // T2 xsX stands alone
+          used = sl < 5u;                                                                    // slot 5 (v^2 w) has no coefficient
+        } else {
+          const uint32_t off = sl == 3u ? 18u : sl == 4u ? 36u : 0u;                        // tower slots of w^0, w^1, w^3: c0 py, c1 px, c2
+          ta = mode == 2 ? fp2_load_mem(ws_at_lane(lnl, off)) : fp2_load_limbs(ws_at_lane(tab, 54u * q + off));
+          tb = ta;
+          sa = fp_select(sl == 4u, fp_one(), fp_load_mem(ws_at_lane(cw, sl == 0u ? 9u : 0u)));
+          sb = fp_zero();
+          used = sl == 0u || sl == 3u || sl == 4u;
+        }
+        a0 = ta.c0; b0 = sa; c0 = tb.c0; d0 = sb; a1 = ta.c1; b1 = sa; c1 = tb.c1; d1 = sb;
+        out = wide_val(W, WV_L + q, sl);
+      }
+      const Fp2 r = {fp_dot2(a0, b0, c0, d0), fp_dot2(a1, b1, c1, d1)};
+      fp2_store_mem(out, fp2_select(used, r, fp2_zero()));
     })
 }
-// Two pairs with the pair table of ell_pair_expanded (pairing.h): e = this step's nine products T0..T8 (162 limbs), cw = the nine
-// coordinate values X, Y, Z, xs X, ys Y, xs Z, ys Z, ys X, xs Y (LDS, 81 limbs):
-//   L = (T0 ysY + T1 Z) + T2 xsX v + (T3 xsZ + T4 X) v^2 + [(T5 ysX + T6 xsY) + (T7 ysZ + T8 Y) v] w
-BN_FUNC void wide_line_eval_pair(const Wide& W, uint32_t dst, const Ws& e, const Ws& cw) {
-  BN_WIDE_PHASE(lane,
-    if (lane < 6u) {
-      const uint32_t s = lane;                                      // tower slot; slot 5 (v^2 w) has no coefficient
-      const uint32_t ta = s == 0u ? 0u : s == 1u ? 2u : s == 2u ? 3u : s == 3u ? 5u : 7u, tb = s == 0u ? 1u : s == 1u ? 2u : s == 2u ? 4u : s == 3u ? 6u : 8u;
-      const uint32_t ca = s == 0u ? 4u : s == 1u ? 3u : s == 2u ? 5u : s == 3u ? 7u : 6u, cb = s == 0u ? 2u : s == 2u ? 0u : s == 3u ? 8u : 1u;
-      const Fp sa = fp_load_mem(ws_at(cw, 9u * ca));
-      const Fp sb = fp_select(s == 1u, fp_zero(), fp_load_mem(ws_at(cw, 9u * cb)));      // T2 xsX stands alone
-      const Fp2 v = fp2_dot_fp(fp2_load_limbs(ws_at(e, 18u * ta)), sa, fp2_load_limbs(ws_at(e, 18u * tb)), sb);
-      fp2_store_mem(wide_val(W, dst, s), fp2_select(s < 5u, v, fp2_zero()));
-    })
-}
-enum : uint32_t { WOP_MUL = 0, WOP_SQR = 1, WOP_CONJ = 2, WOP_COPY = 3, WOP_FROB1 = 4, WOP_FROB2 = 5, WOP_FROB3 = 6 };
+enum : uint32_t { WOP_MUL = 0, WOP_SQR = 1, WOP_CONJ = 2, WOP_COPY = 3, WOP_FROB1 = 4, WOP_FROB2 = 5, WOP_FROB3 = 6, WOP_SUMS = 7 };
 // one primitive; WOP_SQR squares `dst` in place `a` times.  A real function: every primitive is instantiated once.
 BN_HD BN_WIDE_NOINLINE inline void wide_exec(const Wide& W, uint32_t op, uint32_t dst, uint32_t a, uint32_t b) {
   switch (op) {
-    case WOP_MUL: wide_mul(W, dst, a, b); break;
+    case WOP_MUL: wide_mul_products(W, a, b);                       // falls through to the sums: one copy of each phase per kernel
+    case WOP_SUMS: wide_mul_sums(W, dst); break;
     case WOP_SQR: for (uint32_t q = 0; q < a; ++q) wide_cyc_sqr(W, dst); break;
     case WOP_CONJ: wide_conj_or_copy(W, dst, a, true); break;
     case WOP_COPY: wide_conj_or_copy(W, dst, a, false); break;
@@ -166,23 +207,24 @@ BN_HD BN_WIDE_NOINLINE inline void wide_exec(const Wide& W, uint32_t op, uint32_
     default: wide_frob<3>(W, dst, a); break;
   }
 }
-enum : uint32_t { WV_L = 1 };                                       // the line value (the Miller loops do not use WV_T)
 // the loop of miller_loop_1prepared / miller_loop_prepared (pairing.h); pair = false: raw table of 54-limb lines and pt = (px, py);
 // pair = true: pair table of 162-limb entries and pt = the nine coordinate values.  Result in WV_R.
+BN_HD BN_WIDE_NOINLINE inline void wide_mul_products_lines_call(const Wide& W, bool prod, uint32_t a, uint32_t b, uint32_t nlines, const Ws& ln, const Ws& cw, int mode) {
+  wide_mul_products_lines(W, prod, a, b, nlines, ln, cw, mode);      // a real function, like wide_exec: instantiated once per kernel
+}
 BN_HD inline void wide_miller_prepared(const Wide& W, const Ws& table, const Ws& pt, bool pair) {
   BN_WIDE_PHASE(lane,
     if (lane < 6u) fp2_store_mem(wide_val(W, WV_R, lane), lane == 0u ? fp2_one() : fp2_zero());
   )
   const size_t per = pair ? 162 : 54;
   int ti = 0;
-  for (int j = bnc::ATE_NAF_LEN - 2; j >= -2; --j) {                // j = -1, -2: the two final lines (no squaring)
-    if (j >= 0) wide_exec(W, WOP_MUL, WV_R, WV_R, WV_R);
-    const int lines = j >= 0 ? (ate_naf_digit(j) != 0 ? 2 : 1) : 1;
-    for (int q = 0; q < lines; ++q) {
-      const Ws ln = ws_at(table, per * (size_t)ti++);
-      if (pair) wide_line_eval_pair(W, WV_L, ln, pt); else wide_line_eval_1<false>(W, WV_L, ln, pt);
-      wide_exec(W, WOP_MUL, WV_R, WV_R, WV_L);
-    }
+  for (int j = bnc::ATE_NAF_LEN - 2; j >= -1; --j) {                // j = -1: the two final lines (no squaring)
+    const uint32_t lines = j >= 0 ? (ate_naf_digit(j) != 0 ? 2u : 1u) : 2u;
+    // R^2's 36 products and this digit's line values in one phase: the lines depend on the table and the tuple only
+    wide_mul_products_lines_call(W, j >= 0, WV_R, WV_R, lines, ws_at(table, per * (size_t)ti), pt, pair ? 0 : 1);
+    ti += (int)lines;
+    if (j >= 0) wide_exec(W, WOP_SUMS, WV_R, 0, 0);
+    for (uint32_t q = 0; q < lines; ++q) wide_exec(W, WOP_MUL, WV_R, WV_R, WV_L + q);
   }
 }
 
@@ -221,16 +263,16 @@ BN_HD inline void wide_miller_1(const Wide& W, const G2A& q, const Ws& pt, const
 #endif
   for (int j = bnc::ATE_NAF_LEN - 2; j >= -2; --j) {                // j = -1, -2: the two Frobenius additions
     if (j >= 0) {
-      wide_exec(W, WOP_MUL, WV_R, WV_R, WV_R);
-      BN_WIDE_LINE_STEP(true, q.x, q.y)
-      wide_line_eval_1<true>(W, WV_L, lnw, pt);
+      BN_WIDE_LINE_STEP(true, q.x, q.y)                               // T <- 2T and its tangent: independent of R
+      wide_mul_products_lines_call(W, true, WV_R, WV_R, 1u, lnw, pt, 2);      // R^2's products and the tangent's value in one phase
+      wide_exec(W, WOP_SUMS, WV_R, 0, 0);
       wide_exec(W, WOP_MUL, WV_R, WV_R, WV_L);
     }
     const int d = j >= 0 ? ate_naf_digit(j) : 1;
     if (d != 0) {
       const Fp2 ax = j >= 0 ? q.x : j == -1 ? q1x : q2x, ay = j >= 0 ? (d > 0 ? q.y : nqy) : j == -1 ? q1y : q2y;
       BN_WIDE_LINE_STEP(false, ax, ay)
-      wide_line_eval_1<true>(W, WV_L, lnw, pt);
+      wide_mul_products_lines_call(W, false, WV_R, WV_R, 1u, lnw, pt, 2);
       wide_exec(W, WOP_MUL, WV_R, WV_R, WV_L);
     }
   }

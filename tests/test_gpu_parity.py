@@ -787,7 +787,8 @@ def _rand_coeffs(seed, n, per):
     rng = np.random.default_rng(seed)
     a = rng.integers(0, 256, size=(n * per, 32), dtype=np.uint8)
     a[:, 0] %= 0x30
-    edge = [0, 1, synth.P - 1, 2, synth.P - 2]
+    edge = [0, 1, synth.P - 1, 2, synth.P - 2, (synth.P + 1) // 2, (synth.P - 1) // 2, 1 << 29, (1 << 29) - 1, 1 << 58, 1 << 232, (1 << 232) - 1,
+            1 << 253, (1 << 253) - 1, synth.P // 3, 3]            # limb boundaries of the 9 x 29-bit form, long carry runs
     for k, v in enumerate(edge[:min(len(edge), n * per)]):
         a[k] = np.frombuffer(v.to_bytes(32, "big"), dtype=np.uint8)
     return a.tobytes()
@@ -795,7 +796,7 @@ def _rand_coeffs(seed, n, per):
 
 @pytest.mark.parametrize("op,per,n", [
     (0, 1, 1 << 20), (1, 1, 1 << 20), (3, 1, 1 << 20), (4, 1, 1 << 20), (5, 1, 1 << 20), (8, 1, 1 << 20),       # Fp mul sqr add sub neg x9
-    (2, 1, 20000), (6, 1, 20000), (7, 1, 20000),                                                                   # Fp inv sqrt is_square
+    (2, 1, 1 << 17), (6, 1, 20000), (7, 1, 20000),                                                                 # Fp inv (divstep recurrence: 609 steps must do for every input) sqrt is_square
     (16, 2, 1 << 18), (17, 2, 1 << 18), (19, 2, 1 << 18), (20, 2, 1 << 18), (18, 2, 20000), (21, 2, 2000),         # Fp2
     (32, 6, 1 << 17), (33, 6, 1 << 17), (35, 6, 1 << 17), (34, 6, 10000),                                          # Fp6
     (48, 12, 1 << 16), (49, 12, 1 << 16), (51, 12, 1 << 16), (52, 12, 1 << 16), (53, 12, 1 << 16), (54, 12, 1 << 16),
