@@ -8,7 +8,7 @@
 #include "wide.h"
 using namespace bn;
 
-__global__ void __launch_bounds__(64) k_wide_ops(const int32_t* table, uint64_t* out, int reps) {
+__global__ void __launch_bounds__(128) k_wide_ops(const int32_t* table, uint64_t* out, int reps) {
   __shared__ int32_t lds[WIDE_LDS_DWORDS + 81];
   const Wide W(lds);
   const uint32_t lane = threadIdx.x;
@@ -44,7 +44,7 @@ int main() {
   hipMalloc(&out, 16 * 8);
   const int reps = 200;
   for (int blocks : {1, 256, 1024}) {
-    hipLaunchKernelGGL(k_wide_ops, dim3(blocks), dim3(64), 0, 0, table, out, reps);
+    hipLaunchKernelGGL(k_wide_ops, dim3(blocks), dim3(128), 0, 0, table, out, reps);
     hipDeviceSynchronize();
     uint64_t h[16]; hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost);
     const char* names[5] = {"wide_mul", "wide_cyc_sqr", "wide_sqr_with_two_lines", "wide_frob1", "wide_conj"};

@@ -239,6 +239,37 @@ BN_INL Fp fp_lc3(const Fp& x1, const Fp& x2, const Fp& x3) { return fp_lc4<K1, K
 template <int K1, int K2>
 BN_INL Fp fp_lc2(const Fp& x1, const Fp& x2) { return fp_lc3<K1, K2, 0>(x1, x2, x1); }
 
+// r = sum_j k[j] * x[j] with RUN-TIME small integer coefficients (one per lane: the wave-per-tuple sums of wide.h, where the
+// lane's output index decides which partial products enter directly, which times xi = 9 + u): one v_mad_i64_i32 per term and limb
+// with the coefficient in a register, one parallel carry, value brought back to (-eps*p, (1+eps)*p) like fp_lc4's REDUCE form.
+// Replaces select-then-add trees (a select costs as much as the MAD that makes it unnecessary).  sum |k[j]| mag(x[j]) < 2^30.
+template <int N>
+BN_INL Fp fp_lc_rt(const Fp* x, const int32_t* k) {
+  Fp r;
+  int32_t lo[NL], c[NL];
+  int64_t te = 0;
+  BN_UNROLL for (int j = 0; j < N; ++j) te += (int64_t)x[j].l[NL - 1] * k[j];
+  const int32_t q = (int32_t)((te * bnc::LC_QINV) >> 52);
+  BN_UNROLL for (int i = 0; i < NL; ++i) {
+    int64_t t = -(int64_t)q * bnc::P[i];
+    BN_UNROLL for (int j = 0; j < N; ++j) t += (int64_t)x[j].l[i] * k[j];
+    lo[i] = (int32_t)((uint32_t)t & (uint32_t)MASK);
+    c[i] = (int32_t)(t >> RB);
+  }
+  r.l[0] = lo[0];
+  BN_UNROLL for (int i = 1; i < NL - 1; ++i) r.l[i] = lo[i] + c[i - 1];
+  r.l[NL - 1] = lo[NL - 1] + c[NL - 2] + (c[NL - 1] << RB);
+  BN_TRK(++check_stats().lcs; check_stats().lc_terms += N + 1;
+         double m = 0, vb = 0, tin = 0;
+         for (int j = 0; j < N; ++j) { double a = std::fabs((double)k[j]); m += a * mag(x[j]); vb += a * x[j].vb; tin += a * tmag(x[j]); }
+         if (tin >= 7.9) check_fail("fp_lc_rt top-limb estimate: te * LC_QINV must fit 64 bits", tin);
+         double mq = vb + 1; m += mq; vb = 1.0 + (m + 4) / 3171406.0;
+         if (m >= 1.0e9) check_fail("fp_lc_rt 64-bit limb sum", m);
+         double top = vb * P_OVER_R + 1e-7;
+         set_trk(r, -(m + 1) / 536870912.0, 1.0 + (m + 1) / 536870912.0, -top, top, vb); check_actual(r, "fp_lc_rt");)
+  return r;
+}
+
 // ------------------------------------------------------------------ Montgomery products
 // r = (a*b + c*d) / R  (USE_CD = false: r = a*b/R).  Product scanning, one signed 64-bit column
 // accumulator, reduction digits m_k interleaved; the compiler maps every `acc += (int64)x*y` to one

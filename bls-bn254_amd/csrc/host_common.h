@@ -124,9 +124,9 @@ static const size_t TRI_VALUE_LIMBS = 20 * 108;      // tri.h TRI_VALUES x 108
     if ((ctx)->quad_prep && 8 * (size_t)(u) <= (ctx)->lanes_per_round) { L(ctx, "g2_prepare", k_g2_prepare_quad, 2 * 256 * (size_t)nblocks(4 * (size_t)(u)), pks, keys, (uint32_t)(u), raw, ok, d_u); } \
     else { L(ctx, "g2_prepare", k_g2_prepare, 2 * 256 * (size_t)nblocks(u), pks, keys, (uint32_t)(u), raw, ok, d_u); } } while (0)
 
-// one workgroup of 64 lanes (one wave) per element: the wave-per-tuple kernels (wide.h)
+// one workgroup of 128 lanes (two waves) per element: the wave-per-tuple kernels (wide.h)
 #define LAUNCH_WIDE(ctx, name, kernel, n, ...) do { ProfScope ps_(ctx, name); \
-    hipLaunchKernelGGL(kernel, dim3((unsigned)(n)), dim3(64), 0, (ctx)->stream, __VA_ARGS__); } while (0); HIPCHK(ctx, hipGetLastError())
+    hipLaunchKernelGGL(kernel, dim3((unsigned)(n)), dim3(128), 0, (ctx)->stream, __VA_ARGS__); } while (0); HIPCHK(ctx, hipGetLastError())      /* wide.h: WIDE_LANES */
 
 // the same on the context's second stream (events recorded there)
 struct ProfScope2 {

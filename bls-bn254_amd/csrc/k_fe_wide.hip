@@ -1,7 +1,7 @@
 // k_fe_wide.hip -- hard part of the final exponentiation with ONE WAVE PER TUPLE (wide.h): for launches of few tuples (the one
 // final exponentiation of an aggregate verify, single pairings, small batches), where the lane-per-tuple kernels
 // k_fe_expx* / k_fe_h3 are the latency of one lane's serial chain (4.5 ms whatever n <= 65536).  Same values, same bytes.
-// Input: t = f^((p^6-1)(p^2+1)) as k_fe_easy leaves it (limb-major, stride).  Workgroup = 64 lanes = tuple blockIdx.x.
+// Input: t = f^((p^6-1)(p^2+1)) as k_fe_easy leaves it (limb-major, stride).  Workgroup = 128 lanes (two waves) = tuple blockIdx.x.
 //   mode 0: one[i] = (result == 1) && flags ok && subgroup ok  (k_pack_bitmap turns the bytes into the bitmap)
 //   mode 1/2: Gt bytes      mode 3: *is_one (n == 1)      mode 4: gt_bytes[i] = (result == 1)
 #include "wide.h"
@@ -9,7 +9,7 @@
 #include "kernels.h"
 using namespace bn;
 
-__global__ void __launch_bounds__(64) k_fe_hard_wide(const int32_t* t_ws, size_t n, size_t stride, const uint8_t* flags, const uint8_t* sub_ok,
+__global__ void __launch_bounds__(128) k_fe_hard_wide(const int32_t* t_ws, size_t n, size_t stride, const uint8_t* flags, const uint8_t* sub_ok,
                                                      uint8_t* one, uint8_t* gt_bytes, int* is_one, int mode) {
   __shared__ int32_t lds[WIDE_LDS_DWORDS];
   const size_t i = blockIdx.x;                       // uniform over the workgroup

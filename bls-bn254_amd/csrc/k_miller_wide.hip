@@ -3,7 +3,7 @@
 //   k_miller_wide_prepared  = k_miller_prepared (verify: both pairs from the key's pair table), same arguments
 //   k_miller_wide_1p        = k_miller_hpk1p (one pair (H, pk) from the key's raw line table), same arguments
 // Same values as those kernels (multi_miller_loop over prepared terms, pairings.rs:808-857), hence the same bytes.
-// Workgroup = 64 lanes = tuple blockIdx.x.
+// Workgroup = 128 lanes (two waves) = tuple blockIdx.x.
 #include "wide.h"
 #include "lane_ops.h"
 #include "kernels.h"
@@ -20,7 +20,7 @@ __device__ inline void wide_store_result(const Wide& W, int32_t* f_ws, size_t f_
 }
 }  // namespace
 
-__global__ void __launch_bounds__(64) k_miller_wide_prepared(const uint32_t* perm, const uint32_t* kid, const uint8_t* sigs, const int32_t* h_ws, size_t h_stride,
+__global__ void __launch_bounds__(128) k_miller_wide_prepared(const uint32_t* perm, const uint32_t* kid, const uint8_t* sigs, const int32_t* h_ws, size_t h_stride,
                                                              const int32_t* table, const uint8_t* key_ok, size_t n, int32_t* f_ws, uint8_t* flags) {
   __shared__ int32_t lds[WIDE_PA_LIMBS + 108 * 3 + 81];            // product area, R, L, L2, the nine coordinate values
   const size_t s = blockIdx.x;
@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(64) k_miller_wide_prepared(const uint32_t* per
   wide_store_result(W, f_ws, n, s, true);
 }
 
-__global__ void __launch_bounds__(64) k_miller_wide_1p(const int32_t* h_ws, size_t h_stride, const uint32_t* kid, const int32_t* table, const uint8_t* key_ok, size_t n,
+__global__ void __launch_bounds__(128) k_miller_wide_1p(const int32_t* h_ws, size_t h_stride, const uint32_t* kid, const int32_t* table, const uint8_t* key_ok, size_t n,
                                                        int32_t* f_ws, size_t f_stride, uint8_t* flags, const uint8_t* skip) {
   __shared__ int32_t lds[WIDE_PA_LIMBS + 108 * 3 + 18];            // product area, R, L, L2, (px, py)
   const size_t i = blockIdx.x;
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(64) k_miller_wide_1p(const int32_t* h_ws, size
 
 // k_miller_1 (pairing / miller_loop of arbitrary (G1, G2) pairs) with one wave per pair: lane 0 runs the point arithmetic of the
 // variable G2 point, the wave the Fp12 arithmetic.  status as lane_miller_1: bit 0 g1 decodes, bit 1 g2 decodes, bit 2 identity.
-__global__ void __launch_bounds__(64) k_miller_wide_1(const uint8_t* g1, const uint8_t* g2, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status) {
+__global__ void __launch_bounds__(128) k_miller_wide_1(const uint8_t* g1, const uint8_t* g2, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status) {
   __shared__ int32_t lds[WIDE_PA_LIMBS + 108 * 3 + 18 + 54];       // product area, R, L, L2, (px, py), the parked line triple
   const size_t i = blockIdx.x;
   if (i >= n) return;

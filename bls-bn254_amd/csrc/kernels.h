@@ -46,12 +46,12 @@ BN_KERNEL k_fe_expx_h1(const int32_t* in, int32_t* slots, size_t n, size_t strid
 BN_KERNEL k_fe_expx_h2(const int32_t* in, int32_t* slots, size_t n, size_t stride, int32_t* b_in, int32_t* c_out, int32_t* b2_out, int32_t* d2_out);
 BN_KERNEL k_fe_h3(const int32_t* t, const int32_t* a, const int32_t* c, const int32_t* b2, const int32_t* x0, int32_t* tmp, size_t n, size_t stride,
                   const uint8_t* flags, const uint8_t* sub_ok, uint8_t* bitmap, uint8_t* gt_bytes, int* is_one, int mode);
-__global__ void __launch_bounds__(64) k_miller_wide_prepared(const uint32_t* perm, const uint32_t* kid, const uint8_t* sigs, const int32_t* h_ws, size_t h_stride,
+__global__ void __launch_bounds__(128) k_miller_wide_prepared(const uint32_t* perm, const uint32_t* kid, const uint8_t* sigs, const int32_t* h_ws, size_t h_stride,
                                                              const int32_t* table, const uint8_t* key_ok, size_t n, int32_t* f_ws, uint8_t* flags);
-__global__ void __launch_bounds__(64) k_miller_wide_1p(const int32_t* h_ws, size_t h_stride, const uint32_t* kid, const int32_t* table, const uint8_t* key_ok, size_t n,
+__global__ void __launch_bounds__(128) k_miller_wide_1p(const int32_t* h_ws, size_t h_stride, const uint32_t* kid, const int32_t* table, const uint8_t* key_ok, size_t n,
                                                        int32_t* f_ws, size_t f_stride, uint8_t* flags, const uint8_t* skip);
-__global__ void __launch_bounds__(64) k_miller_wide_1(const uint8_t* g1, const uint8_t* g2, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status);
-__global__ void __launch_bounds__(64) k_fe_hard_wide(const int32_t* t_ws, size_t n, size_t stride, const uint8_t* flags, const uint8_t* sub_ok,
+__global__ void __launch_bounds__(128) k_miller_wide_1(const uint8_t* g1, const uint8_t* g2, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status);
+__global__ void __launch_bounds__(128) k_fe_hard_wide(const int32_t* t_ws, size_t n, size_t stride, const uint8_t* flags, const uint8_t* sub_ok,
                                                      uint8_t* one, uint8_t* gt_bytes, int* is_one, int mode);
 BN_KERNEL k_fp12_from_bytes(const uint8_t* in, size_t n, int32_t* f_ws, size_t f_stride, uint8_t* status);
 BN_KERNEL k_fp12_to_bytes(const int32_t* f_ws, size_t n, size_t stride, uint8_t* out);

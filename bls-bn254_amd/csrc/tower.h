@@ -204,7 +204,7 @@ BN_INL Fp fp_load_mem(const Ws& w) {
   return r;
 }
 BN_INL void fp_store_mem(const Ws& w, const Fp& a) {
-  BN_TRK(if (a.lo < -1e-6 || a.hi > 1.0 + 1e-6) check_fail("fp_store_mem needs a normalised value", mag(a));
+  BN_TRK(if (a.lo < -4e-6 || a.hi > 1.0 + 4e-6) check_fail("fp_store_mem needs a normalised value", mag(a));      // a carry pass leaves limbs within a few thousand units of [0, 2^29]; the proven interval travels with the value (park_trk)
          { std::lock_guard<std::mutex> g(park_mutex()); park_trk()[ws_addr(w, 0)] = ParkTrk{a.lo, a.hi, a.tlo, a.thi, a.vb}; })
   BN_UNROLL for (int k = 0; k < NL; ++k) ws_store(w, k, a.l[k]);
 }

@@ -1,30 +1,34 @@
-// wide.h -- ONE WAVE PER TUPLE arithmetic for the latency-bound tails of the path.
+// wide.h -- TWO WAVES PER TUPLE arithmetic for the latency-bound tails of the path ("wave-per-tuple" in the documents: one
+// workgroup of 128 lanes per tuple; one wave until the end of round 3).
 //
 // The verification kernels run one lane per tuple: right for throughput, but a launch with few tuples (the ONE final
 // exponentiation of an aggregate verify, a single pairing, a small batch) is then the latency of one lane's serial chain --
 // 4.5 ms for the hard part of the final exponentiation (pairings.rs:117-178), whatever the batch size below 65 536.
-// Here the 64 lanes of a wave share one tuple: an Fp12 value lives in LDS as six Fp2 coefficients, an Fp12 product is 36
-// independent Fp2 products (one per lane) followed by six sums (w^6 = xi wraps the high half), a Granger-Scott cyclotomic
-// squaring (pairings.rs:68-115) is nine independent Fp2 squarings followed by six combinations.  Same field values as the
-// serial code (tower.h), hence the same bytes after the final canonicalisation; about 7 x shorter chains.
+// Here the 128 lanes of a workgroup share one tuple, and the unit of work of a lane is ONE Fp output: an Fp12 value lives in LDS
+// as six Fp2 coefficients; an Fp12 product is 72 independent double products (the two components of the 36 Fp2 products a_i b_j,
+// one per lane) followed by twelve linear combinations (w^6 = xi wraps the high half: per-lane coefficients, fp_lc_rt); a
+// Granger-Scott cyclotomic squaring (pairings.rs:68-115) is eighteen independent Fp products (the two components of nine Fp2
+// squarings) followed by twelve linear combinations.  Same field values as the serial code (tower.h), hence the same bytes after
+// the final canonicalisation; chains ~15 x shorter than a lane's.
 //
 // Everything is written as PHASES: within a phase every lane works on its own operands and writes its own result; a
-// phase boundary is a workgroup barrier on the device (the workgroup is one wave) and the end of a loop over the 64 lane
-// ids in tests/hostsim, which runs this same code under the interval checker.
+// phase boundary is a workgroup barrier on the device and the end of a loop over the lane ids in tests/hostsim, which runs
+// this same code under the interval checker.
 #pragma once
 #include "quad.h"
 
 namespace bn {
 
+constexpr uint32_t WIDE_LANES = 128;
 #if defined(__HIP_DEVICE_COMPILE__)
-#define BN_WIDE_PHASE(lane, ...) { const uint32_t lane = threadIdx.x & 63u; { __VA_ARGS__ } __syncthreads(); }
+#define BN_WIDE_PHASE(lane, ...) { const uint32_t lane = threadIdx.x; { __VA_ARGS__ } __syncthreads(); }
 #define BN_WIDE_NOINLINE __attribute__((noinline))
 #else
-#define BN_WIDE_PHASE(lane, ...) { for (uint32_t lane = 0; lane < 64u; ++lane) { __VA_ARGS__ } }
+#define BN_WIDE_PHASE(lane, ...) { for (uint32_t lane = 0; lane < WIDE_LANES; ++lane) { __VA_ARGS__ } }
 #define BN_WIDE_NOINLINE
 #endif
 
-// LDS region of one wave (dwords): the product area (36 Fp2) and WIDE_VALUES Fp12 values of 108 limbs, each stored as
+// LDS region of one tuple (dwords): the product area (36 Fp2) and WIDE_VALUES Fp12 values of 108 limbs, each stored as
 // its six tower slots c0.c0, c0.c1, c0.c2, c1.c0, c1.c1, c1.c2 (18 limbs per slot).
 enum : uint32_t { WIDE_PA_LIMBS = 36 * 18, WIDE_VALUES = 20, WIDE_LDS_DWORDS = WIDE_PA_LIMBS + 108 * WIDE_VALUES };
 // value ids of the hard part
@@ -51,64 +55,91 @@ BN_INL uint32_t wide_slot_of_w(uint32_t k) { return (k & 1u) ? 3u + (k >> 1) : (
 // tower slot of z_i in the Granger-Scott labelling (z0 = c0.c0, z4 = c0.c1, z3 = c0.c2, z2 = c1.c0, z1 = c1.c1, z5 = c1.c2)
 BN_INL uint32_t wide_slot_of_z(uint32_t i) { return i == 0 ? 0u : i == 1 ? 4u : i == 2 ? 3u : i == 3 ? 2u : i == 4 ? 1u : 5u; }
 
-// x1 + ... + x6 per component, normalised (two passes)
-BN_INL Fp2 wide_sum6(const Fp2& a, const Fp2& b, const Fp2& c, const Fp2& d, const Fp2& e, const Fp2& f) {
-  Fp2 s = {fp_lc4<1, 1, 1, 1>(a.c0, b.c0, c.c0, d.c0), fp_lc4<1, 1, 1, 1>(a.c1, b.c1, c.c1, d.c1)};
-  return {fp_lc3<1, 1, 1>(s.c0, e.c0, f.c0), fp_lc3<1, 1, 1>(s.c1, e.c1, f.c1)};
+// canonical limbs of ONE Fp from a table (the Fp-granular form of fp2_load_limbs, pairing.h)
+BN_INL Fp fp_load_limbs_ws(const Ws& w) {
+  Fp c;
+  BN_UNROLL for (int k = 0; k < NL; ++k) c.l[k] = ws_load(w, k);
+  BN_TRK(set_trk(c, 0, 1, 0, 0.006, 1);)
+  return c;
 }
-
-// dst = a * b.  Phase 1: lane (i, j) forms a_i b_j (coefficients of w^i, w^j).  Phase 2 (wide_mul_sums): lane k sums the
-// products with i + j = k and xi times those with i + j = k + 6.  dst may be a or b.
+// dst = a * b.  Phase 1 (wide_mul_products): lane 2 (6 i + j) + h forms component h of a_i b_j (coefficients of w^i, w^j): ONE
+// double product, x0 y0 + (-x1) y1 or x0 y1 + x1 y0.  Phase 2 (wide_mul_sums): lane 2 k + h forms component h of the coefficient
+// of w^k: the products with i + j = k and xi times those with i + j = k + 6, as ONE linear combination with per-lane
+// coefficients (fp_lc_rt): with t_i = a_i b_(k-i mod 6), direct for i <= k and wrapped (times xi = 9 + u) for i > k,
+//   out.c0 = sum_i A_i t_i.c0 - W_i t_i.c1,   out.c1 = sum_i A_i t_i.c1 + W_i t_i.c0,   A_i = 1 | 9, W_i = 0 | 1.
+// dst may be a or b.
 BN_FUNC void wide_mul_sums(const Wide& W, uint32_t dst) {
   BN_WIDE_PHASE(lane,
-    if (lane < 6u) {
-      const uint32_t k = lane;
-      const Fp2 zero = fp2_zero();
-      Fp2 t[6];
-      BN_UNROLL for (uint32_t i = 0; i < 6u; ++i) t[i] = fp2_load_mem(wide_pa(W, 6u * i + (k + 6u - i) % 6u));
-      const Fp2 sd = wide_sum6(t[0], fp2_select(1u <= k, t[1], zero), fp2_select(2u <= k, t[2], zero), fp2_select(3u <= k, t[3], zero),
-                               fp2_select(4u <= k, t[4], zero), fp2_select(5u <= k, t[5], zero));
-      const Fp2 sw = wide_sum6(zero, fp2_select(1u > k, t[1], zero), fp2_select(2u > k, t[2], zero), fp2_select(3u > k, t[3], zero),
-                               fp2_select(4u > k, t[4], zero), fp2_select(5u > k, t[5], zero));
-      fp2_store_mem(wide_val(W, dst, wide_slot_of_w(k)), fp2_add_mul_xi(sd, sw));
+    if (lane < 12u) {
+      const uint32_t k = lane >> 1, h = lane & 1u;
+      Fp x[12];
+      int32_t kk[12];
+      BN_UNROLL for (uint32_t i = 0; i < 6u; ++i) {
+        const Fp2 t = fp2_load_mem(wide_pa(W, 6u * i + (k + 6u - i) % 6u));
+        const bool wrap = i > k;
+        x[i] = t.c0; x[6 + i] = t.c1;
+        kk[i] = h ? (wrap ? 1 : 0) : (wrap ? 9 : 1);
+        kk[6 + i] = h ? (wrap ? 9 : 1) : (wrap ? -1 : 0);
+      }
+      fp_store_mem(ws_at_lane(wide_val(W, dst, wide_slot_of_w(k)), 9u * h), fp_lc_rt<12>(x, kk));
     })
+}
+// the operands of product lane `pl` (< 72) of a * b as a double product a0 b0 + c0 d0, and where its result goes
+BN_INL Ws wide_product_operands(const Wide& W, uint32_t pl, uint32_t a, uint32_t b, Fp& a0, Fp& b0, Fp& c0, Fp& d0) {
+  const uint32_t pidx = pl >> 1, h = pl & 1u, i = pidx / 6u, j = pidx - 6u * i;
+  const Ws xw = wide_val(W, a, wide_slot_of_w(i)), yw = wide_val(W, b, wide_slot_of_w(j));
+  const Fp x1 = fp_load_mem(ws_at(xw, 9));
+  a0 = fp_load_mem(xw);
+  b0 = fp_load_mem(ws_at_lane(yw, 9u * h));                    // h = 0: y0, h = 1: y1
+  c0 = fp_select(h != 0u, x1, fp_neg(x1));                     // h = 0: -x1, h = 1: x1
+  d0 = fp_load_mem(ws_at_lane(yw, 9u * (1u - h)));             // h = 0: y1, h = 1: y0
+  return ws_at_lane(wide_pa(W, pidx), 9u * h);
 }
 BN_FUNC void wide_mul_products(const Wide& W, uint32_t a, uint32_t b) {
   BN_WIDE_PHASE(lane,
-    if (lane < 36u) {
-      const uint32_t i = lane / 6u, j = lane - 6u * i;
-      const Fp2 x = fp2_load_mem(wide_val(W, a, wide_slot_of_w(i))), y = fp2_load_mem(wide_val(W, b, wide_slot_of_w(j)));
-      fp2_store_mem(wide_pa(W, lane), fp2_mul(x, y));
+    if (lane < 72u) {
+      Fp a0, b0, c0, d0;
+      const Ws out = wide_product_operands(W, lane, a, b, a0, b0, c0, d0);
+      fp_store_mem(out, fp_dot2(a0, b0, c0, d0));
     })
 }
 BN_FUNC void wide_mul(const Wide& W, uint32_t dst, uint32_t a, uint32_t b) { wide_mul_products(W, a, b); wide_mul_sums(W, dst); }
-// v = v^2 for v in the cyclotomic subgroup (same values as fp12_cyclotomic_sqr, tower.h).  Phase 1: lane (pair p, kind q)
-// squares a, b or a + b of the pair (z0, z1), (z2, z3), (z4, z5).  Phase 2: lane o forms r_o in the slot of z_o.
+// v = v^2 for v in the cyclotomic subgroup (same values as fp12_cyclotomic_sqr, tower.h).  Phase 1: lane 2 (3 p + q) + h forms
+// component h of the square of a, b or a + b (q = 0, 1, 2) of the pair p: (z0, z1), (z2, z3), (z4, z5) -- one Fp product,
+// (u0 + u1)(u0 - u1) or 2 u0 u1.  Phase 2: lane 2 o + h forms component h of r_o in the slot of z_o from the pair's ta = a^2,
+// tb = b^2, s = (a + b)^2 and the old z_o: cyc_c0 / cyc_c1 / the z2 formula of fp12_cyclotomic_sqr (tower.h) written out per
+// component as seven-term combinations:
+//   r0, r4, r3 (cyc_c0):  c0 = 3 ta0 + 27 tb0 - 3 tb1 - 2 z0,   c1 = 3 ta1 + 3 tb0 + 27 tb1 - 2 z1
+//   r1, r5     (cyc_c1):  c = 3 s - 3 ta - 3 tb + 2 z   (per component)
+//   r2 = 3 xi (s - ta - tb) + 2 z2:  c0 = 27 (s0 - ta0 - tb0) - 3 (s1 - ta1 - tb1) + 2 z0,  c1 = 3 (s0 - ta0 - tb0) + 27 (s1 - ta1 - tb1) + 2 z1
 BN_FUNC void wide_cyc_sqr(const Wide& W, uint32_t v) {
   BN_WIDE_PHASE(lane,
-    if (lane < 9u) {
-      const uint32_t p = lane / 3u, q = lane - 3u * p;
+    if (lane < 18u) {
+      const uint32_t sq = lane >> 1, h = lane & 1u, p = sq / 3u, q = sq - 3u * p;
       const Fp2 a = fp2_load_mem(wide_val(W, v, wide_slot_of_z(2u * p))), b = fp2_load_mem(wide_val(W, v, wide_slot_of_z(2u * p + 1u)));
       const Fp2 s = fp2_norm(fp2_add(a, b));
-      fp2_store_mem(wide_pa(W, lane), fp2_sqr(fp2_select(q == 0u, a, fp2_select(q == 1u, b, s))));
+      const Fp2 u = fp2_select(q == 0u, a, fp2_select(q == 1u, b, s));
+      // fp2_sqr (tower.h) one component per lane: (u0 + u1)(u0 - u1) | (2 u0) u1
+      const Fp m0 = fp_select(h != 0u, fp_dbl(u.c0), fp_add(u.c0, u.c1)), m1 = fp_select(h != 0u, u.c1, fp_sub(u.c0, u.c1));
+      fp_store_mem(ws_at_lane(wide_pa(W, sq), 9u * h), fp_mul(m0, m1));
     })
   BN_WIDE_PHASE(lane,
-    if (lane < 6u) {
-      const uint32_t o = lane;
+    if (lane < 12u) {
+      const uint32_t o = lane >> 1, h = lane & 1u;
       const uint32_t p = (o < 2u) ? 0u : (o < 4u) ? 2u : 1u;       // r0, r1 <- (z0, z1); r2, r3 <- (z4, z5); r4, r5 <- (z2, z3)
-      const Fp4Sq q = {fp2_load_mem(wide_pa(W, 3u * p)), fp2_load_mem(wide_pa(W, 3u * p + 1u)), fp2_load_mem(wide_pa(W, 3u * p + 2u))};
-      const Ws zw = wide_val(W, v, wide_slot_of_z(o));
-      const Fp2 z = fp2_load_mem(zw);
-      Fp2 r;
-      if (o == 2u) {                                              // z2 = 3 xi t5 + 2 z2, t5 = s - ta - tb brought back below ~p first
-        const Fp2 t5 = {fp_lc4<1, -1, -1, 0, true>(q.s.c0, q.ta.c0, q.tb.c0, q.s.c0), fp_lc4<1, -1, -1, 0, true>(q.s.c1, q.ta.c1, q.tb.c1, q.s.c1)};
-        r = {fp_lc3<27, -3, 2>(t5.c0, t5.c1, z.c0), fp_lc3<3, 27, 2>(t5.c0, t5.c1, z.c1)};
-      } else if (o == 1u || o == 5u) {
-        r = cyc_c1(q, z);
-      } else {
-        r = cyc_c0(q, z);
+      const Fp2 ta = fp2_load_mem(wide_pa(W, 3u * p)), tb = fp2_load_mem(wide_pa(W, 3u * p + 1u)), s = fp2_load_mem(wide_pa(W, 3u * p + 2u));
+      const Ws zw = ws_at_lane(wide_val(W, v, wide_slot_of_z(o)), 9u * h);
+      const Fp x[7] = {ta.c0, ta.c1, tb.c0, tb.c1, s.c0, s.c1, fp_load_mem(zw)};
+      const int kind = o == 2u ? 2 : (o == 1u || o == 5u) ? 1 : 0;
+      const int32_t tab[3][2][7] = {{{3, 0, 27, -3, 0, 0, -2}, {0, 3, 3, 27, 0, 0, -2}},
+                                    {{-3, 0, -3, 0, 3, 0, 2}, {0, -3, 0, -3, 0, 3, 2}},
+                                    {{-27, 3, -27, 3, 27, -3, 2}, {-3, -27, -3, -27, 3, 27, 2}}};
+      int32_t kk[7];
+      BN_UNROLL for (int t = 0; t < 7; ++t) {
+        const int32_t c0 = h ? tab[0][1][t] : tab[0][0][t], c1 = h ? tab[1][1][t] : tab[1][0][t], c2 = h ? tab[2][1][t] : tab[2][0][t];
+        kk[t] = kind == 0 ? c0 : kind == 1 ? c1 : c2;
       }
-      fp2_store_mem(zw, fp2_norm(r));
+      fp_store_mem(zw, fp_lc_rt<7>(x, kk));
     })
 }
 // dst = conj(src) = (c0, -c1); dst = src (plain copy) when neg is false
@@ -142,55 +173,50 @@ BN_FUNC void wide_frob(const Wide& W, uint32_t dst, uint32_t src) {
 // two pairs: L = (T0 ysY + T1 Z) + T2 xsX v + (T3 xsZ + T4 X) v^2 + [(T5 ysX + T6 xsY) + (T7 ysZ + T8 Y) v] w from the pair table
 // entry T0..T8 of ell_pair_expanded (pairing.h) and the nine coordinate values X, Y, Z, xs X, ys Y, xs Z, ys Z, ys X, xs Y.
 // The product phase of dst = a * b (wide_mul's phase 1) with up to TWO line values evaluated by otherwise idle lanes in the SAME
-// instruction stream: an Fp2 product and a line coefficient are both a pair of double products,
-//   product lane (i, j):  { x0 y0 + (-x1) y1,  x0 y1 + x1 y0 }            line lane (q, s):  { TA0 sa + TB0 sb,  TA1 sa + TB1 sb }
-// so every lane first fetches ITS eight operands (the only divergent part: a few loads) and then all run the same two fp_dot2.
-// Lanes 0..35 form the products (skipped when `prod` is false: the two final lines have no squaring), lanes 36 + 6 q + s the
-// coefficient of tower slot s of line q, written to value WV_L + q.  Line operands:
-//   mode 0: pair table entry (162 limbs, T0..T8) at ln (+ 162 q), cw = the nine coordinate values (wide_line_eval_pair)
-//   mode 1: raw triple (54 limbs) at ln (+ 54 q), cw = (px, py)                                    (wide_line_eval_1<false>)
-//   mode 2: the triple parked in LDS by fp2_store_mem at ln, cw = (px, py); one line                (wide_line_eval_1<true>)
+// instruction stream: a component of an Fp2 product and a component of a line coefficient are both ONE double product,
+//   product lane:  x0 y0 + (-x1) y1  |  x0 y1 + x1 y0            line lane (q, s, h):  TA_h sa + TB_h sb
+// so every lane first fetches ITS four operands (the only divergent part: a few loads) and then all run the same fp_dot2.
+// Lanes 0..71 form the products (skipped when `prod` is false: the two final lines have no squaring), lane 72 + 12 q + 2 s + h
+// component h of the coefficient of tower slot s of line q, written to value WV_L + q.  Line operands:
+//   mode 0: pair table entry (162 limbs, T0..T8) at ln (+ 162 q), cw = the nine coordinate values
+//           L = (T0 ysY + T1 Z) + T2 xsX v + (T3 xsZ + T4 X) v^2 + [(T5 ysX + T6 xsY) + (T7 ysZ + T8 Y) v] w
+//   mode 1: raw triple (54 limbs) at ln (+ 54 q), cw = (px, py):  L = c0 py + c1 px w + c2 w^3
+//   mode 2: the triple parked in LDS by fp2_store_mem at ln, cw = (px, py); one line
 // wide_mul_sums(dst) (wide_mul's phase 2) completes the product.
 enum : uint32_t { WV_L = 1, WV_L2 = 2 };                            // the line values (the Miller loops do not use WV_T, WV_A)
 BN_FUNC void wide_mul_products_lines(const Wide& W, bool prod, uint32_t a, uint32_t b, uint32_t nlines, const Ws& ln_in, const Ws& cw_in, int mode) {
   // This is a real function: what the kernel knows about its references is restated here -- the key's table is buffer-addressed,
-  // dense (stride 1) and one base for the whole wave; the coordinates and a parked line live in the wave's LDS region.
+  // dense (stride 1) and one base for the whole workgroup; the coordinates and a parked line live in the tuple's LDS region.
   const Ws tab = {ws_uniform(ln_in).base, 1, ln_in.lane4, true}, lnl = wide_local(W, ln_in), cw = wide_local(W, cw_in);
   BN_WIDE_PHASE(lane,
-    const bool is_prod = prod && lane < 36u, is_line = lane >= 36u && lane < 36u + 6u * nlines;
+    const bool is_prod = prod && lane < 72u, is_line = lane >= 72u && lane < 72u + 12u * nlines;
     if (is_prod || is_line) {
-      Fp a0, b0, c0, d0, a1, b1, c1, d1;
+      Fp a0, b0, c0, d0;
       bool used = true;
       Ws out;
       if (is_prod) {
-        const uint32_t i = lane / 6u, j = lane - 6u * i;
-        const Fp2 x = fp2_load_mem(wide_val(W, a, wide_slot_of_w(i))), y = fp2_load_mem(wide_val(W, b, wide_slot_of_w(j)));
-        a0 = x.c0; b0 = y.c0; c0 = fp_neg(x.c1); d0 = y.c1; a1 = x.c0; b1 = y.c1; c1 = x.c1; d1 = y.c0;
-        out = wide_pa(W, lane);
+        out = wide_product_operands(W, lane, a, b, a0, b0, c0, d0);
       } else {
-        const uint32_t q = (lane - 36u) / 6u, sl = lane - 36u - 6u * q;      // line, tower slot
-        Fp2 ta, tb;
-        Fp sa, sb;
+        const uint32_t q = (lane - 72u) / 12u, r = lane - 72u - 12u * q, sl = r >> 1, h = r & 1u;      // line, tower slot, component
         if (mode == 0) {
           const uint32_t ia = sl == 0u ? 0u : sl == 1u ? 2u : sl == 2u ? 3u : sl == 3u ? 5u : 7u, ib = sl == 0u ? 1u : sl == 1u ? 2u : sl == 2u ? 4u : sl == 3u ? 6u : 8u;
           const uint32_t ca = sl == 0u ? 4u : sl == 1u ? 3u : sl == 2u ? 5u : sl == 3u ? 7u : 6u, cb = sl == 0u ? 2u : sl == 2u ? 0u : sl == 3u ? 8u : 1u;
-          ta = fp2_load_limbs(ws_at_lane(tab, 162u * q + 18u * ia)); tb = fp2_load_limbs(ws_at_lane(tab, 162u * q + 18u * ib));
-          sa = fp_load_mem(ws_at_lane(cw, 9u * ca));
-          sb = fp_select(sl == 1u, fp_zero(), fp_load_mem(ws_at_lane(cw, 9u * cb)));      // T2 xsX stands alone
+          a0 = fp_load_limbs_ws(ws_at_lane(tab, 162u * q + 18u * ia + 9u * h)); c0 = fp_load_limbs_ws(ws_at_lane(tab, 162u * q + 18u * ib + 9u * h));
+          b0 = fp_load_mem(ws_at_lane(cw, 9u * ca));
+          d0 = fp_select(sl == 1u, fp_zero(), fp_load_mem(ws_at_lane(cw, 9u * cb)));      // T2 xsX stands alone
           used = sl < 5u;                                                                    // slot 5 (v^2 w) has no coefficient
         } else {
-          const uint32_t off = sl == 3u ? 18u : sl == 4u ? 36u : 0u;                        // tower slots of w^0, w^1, w^3: c0 py, c1 px, c2
-          ta = mode == 2 ? fp2_load_mem(ws_at_lane(lnl, off)) : fp2_load_limbs(ws_at_lane(tab, 54u * q + off));
-          tb = ta;
-          sa = fp_select(sl == 4u, fp_one(), fp_load_mem(ws_at_lane(cw, sl == 0u ? 9u : 0u)));
-          sb = fp_zero();
+          const uint32_t off = (sl == 3u ? 18u : sl == 4u ? 36u : 0u) + 9u * h;             // tower slots of w^0, w^1, w^3: c0 py, c1 px, c2
+          a0 = mode == 2 ? fp_load_mem(ws_at_lane(lnl, off)) : fp_load_limbs_ws(ws_at_lane(tab, 54u * q + off));
+          c0 = a0;
+          b0 = fp_select(sl == 4u, fp_one(), fp_load_mem(ws_at_lane(cw, sl == 0u ? 9u : 0u)));
+          d0 = fp_zero();
           used = sl == 0u || sl == 3u || sl == 4u;
         }
-        a0 = ta.c0; b0 = sa; c0 = tb.c0; d0 = sb; a1 = ta.c1; b1 = sa; c1 = tb.c1; d1 = sb;
-        out = wide_val(W, WV_L + q, sl);
+        out = ws_at_lane(wide_val(W, WV_L + q, sl), 9u * h);
       }
-      const Fp2 r = {fp_dot2(a0, b0, c0, d0), fp_dot2(a1, b1, c1, d1)};
-      fp2_store_mem(out, fp2_select(used, r, fp2_zero()));
+      const Fp r = fp_dot2(a0, b0, c0, d0);
+      fp_store_mem(out, fp_select(used, r, fp_zero()));
     })
 }
 enum : uint32_t { WOP_MUL = 0, WOP_SQR = 1, WOP_CONJ = 2, WOP_COPY = 3, WOP_FROB1 = 4, WOP_FROB2 = 5, WOP_FROB3 = 6, WOP_SUMS = 7 };
@@ -254,7 +280,7 @@ BN_HD inline void wide_miller_1(const Wide& W, const G2A& q, const Ws& pt, const
   const Fp2 q2y = fp2_norm(fp2_neg(fp2_mul(fp2_norm(fp2_conj(q1y)), g3)));                                  // -pi^2(Q)
 #if defined(__HIP_DEVICE_COMPILE__)
   G2J T = {q.x, q.y, fp2_one()};
-#define BN_WIDE_LINE_STEP(DBL, AX, AY) { const uint32_t lane_ = threadIdx.x & 63u; \
+#define BN_WIDE_LINE_STEP(DBL, AX, AY) { const uint32_t lane_ = threadIdx.x; \
     if (lane_ < 4u) { const Line l_ = fp2_norm_line((DBL) ? quad_doubling_step(T, lane_) : quad_addition_step(T, AX, AY, lane_)); if (lane_ == 0u) line_store(lnw, l_); } \
     __syncthreads(); }
 #else

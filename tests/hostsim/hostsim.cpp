@@ -172,7 +172,7 @@ int hs_fe_easy_split_matches(const uint8_t* in, int slot) {
   fp12_to_be(b, fe_easy(f));
   return std::memcmp(a, b, 384) == 0 ? 1 : 0;
 }
-// wide.h (one wave per tuple) under the interval checker: the 64 lanes of a phase run one after the other over a host
+// wide.h (one workgroup of 128 lanes per tuple) under the interval checker: the lanes of a phase run one after the other over a host
 // array standing in for the wave's LDS region.  Final exponentiation = serial easy part + wide hard part.
 static void wide_put(const Wide& W, uint32_t v, const Fp12& f) {
   const Fp6* h[2] = {&f.c0, &f.c1};
