@@ -189,7 +189,7 @@ int blsbn254_verify_batch_rlc_dev(blsbn254_ctx* ctx, const uint8_t* d_pks, const
  * most 32 when the larger chunk saves a whole round of waves on the device (chunk count just above a multiple of CUs x 256) */
 int blsbn254_set_rlc_group(blsbn254_ctx* ctx, size_t group);
 /* The key round (on by default; BLSBN254_RLC_KEY_ROUND=0 or blsbn254_set_rlc_key_round(ctx, 0) skips it): before any chunk is
- * checked, ALL tuples of every key are checked as one virtual tuple per key -- u checks, run with one wave per check.  A batch
+ * checked, ALL tuples of every key are checked as one virtual tuple per key -- u checks, run with one workgroup (two waves) per check.  A batch
  * without invalid signatures, the usual case, is decided there (262144 tuples over 1024 keys: 9.5 instead of 16.3 ms); if any key
  * fails, only the chunks of the failed keys are checked as described above (the key round then cost about 5 ms extra; a caller
  * whose batches keep failing it does not keep paying: after a failure the next 2, then 4, 8, 16 batches skip it, a pass resets
@@ -290,7 +290,7 @@ int blsbn254_g2_decompress_batch(blsbn254_ctx* ctx, const uint8_t* in /* n*64 */
  * always (a caller that only synchronises the raw stream of blsbn254_ctx_stream must not rely on it).  Up to four calls stay in
  * flight; the caller's device buffers must stay untouched until blsbn254_ctx_synchronize.  BLSBN254_ASYNC_VERIFY=0 or
  * blsbn254_set_async_verify(ctx, 0) makes every call count first; blsbn254_async_stats: out[0] chunks enqueued on the
- * assumption, out[1] of them re-run.  Launch size picks the kernels: up to 2048 tuples one wave per tuple,
+ * assumption, out[1] of them re-run.  Launch size picks the kernels: up to 2048 tuples one workgroup of two waves per tuple,
  * up to 16384 three lanes per tuple, beyond one lane per tuple -- same values, same bitmap. */
 int blsbn254_set_async_verify(blsbn254_ctx* ctx, int on);
 int blsbn254_async_stats(blsbn254_ctx* ctx, uint64_t out[2] /* enqueued on the assumption, re-run */);
