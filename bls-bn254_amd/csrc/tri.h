@@ -125,7 +125,7 @@ BN_INL uint32_t tri_arole(uint32_t role) { return role < 1u ? 0u : 1u; }
 // A workspace reference moved by a LANE-DEPENDENT number of limbs: the offset goes into the per-lane byte offset.  (ws_at moves
 // the base, which buffer addressing keeps in scalar registers: a base that differs between the lanes of a wave would have to be
 // serialised lane by lane.)  limbs * stride * 4 must fit 32 bits together with the lane's own offset.
-BN_INL Ws ws_at_lane(const Ws& w, uint32_t limbs) { return {w.base, w.stride, w.lane4 + limbs * (uint32_t)w.stride * 4u, w.buf}; }
+BN_INL Ws ws_at_lane(const Ws& w, uint32_t limbs) { return {w.base, w.stride, w.lane4 + limbs * (uint32_t)w.stride * 4u, w.buf, w.vfold}; }
 // canonical limbs: the exchange format with the one-lane-per-tuple kernels (f_ws, the easy part's output)
 BN_INL Fp6 tri_load_canon(const Ws& w, uint32_t role) {
   const Ws h = ws_at_lane(w, 54u * tri_arole(role));
@@ -196,7 +196,9 @@ BN_FUNC Fp6 tri_miller_prepared(const Ws& cw, const Ws& ktab_in, uint32_t role) 
 // three t -> t^x chains (pairing.h), with the accumulator R in registers and the named values parked in `vals`
 // (TRI_VALUES x 108 limbs per tuple, limb-major).
 enum : uint32_t { TV_T = 0, TV_A = 1, TV_B = 2, TV_C = 3, TV_B2 = 4, TV_D2 = 5, TV_X = 6, TV_E = 7, TV_D = 8, TV_TMP = 9, TV_SLOT0 = 10, TRI_VALUES = 20 };
-BN_INL Ws tri_val(const Ws& vals, uint32_t v) { return ws_at(vals, 108u * (size_t)v); }
+// (ws_uniform: v comes from the chain's program table, and the 64-bit base arithmetic on it may be done in vector registers -- the
+// base would then pass for lane-dependent and every access be wrapped in a read-first-lane loop: 1377 of them in k_fe_tri_hard)
+BN_INL Ws tri_val(const Ws& vals, uint32_t v) { return ws_uniform(ws_at(vals, 108u * (size_t)v)); }
 BN_FUNC Fp6 tri_exp_x(const Fp6& in, const Ws& vals, uint32_t role) {
   const ChainOp prog[BN_X_CHAIN_LEN] = BN_X_CHAIN;
   Ws vw = vals;
@@ -205,7 +207,7 @@ BN_FUNC Fp6 tri_exp_x(const Fp6& in, const Ws& vals, uint32_t role) {
   Fp6 r = in;
   for (int k = 0; k < BN_X_CHAIN_LEN; ++k) {
     const ChainOp op = prog[k];
-    BN_OPAQUE(vw);
+    BN_OPAQUE_S(vw);
     if (op.load >= 0) r = tri_load(tri_val(vw, TV_SLOT0 + (uint32_t)op.load), role);
     for (int q = 0; q < op.sq; ++q) r = tri_cyc_sqr(r, role);
     if (op.mul >= 0) r = tri_mul(r, tri_load(tri_val(vw, TV_SLOT0 + (uint32_t)op.mul), role), role);
@@ -226,26 +228,26 @@ BN_FUNC Fp6 tri_fe_hard(const Fp6& t, const Ws& vals_in, uint32_t role) {
   tri_store(tri_val(vals, TV_B), b, role);
   BN_MEM_FENCE;
   x = tri_exp_x(b, vals, role);                                                              // t^(-6x^2)
-  BN_OPAQUE(vals);
+  BN_OPAQUE_S(vals);
   const Fp6 c = tri_conj(x, role);                                                           // c = t^(6x^2)
   tri_store(tri_val(vals, TV_C), c, role);
   const Fp6 b2 = tri_mul(c, tri_conj(tri_load(tri_val(vals, TV_B), role), role), role);      // b2 = c conj(b)
   tri_store(tri_val(vals, TV_B2), b2, role);
   BN_MEM_FENCE;
   x = tri_exp_x(tri_cyc_sqr(c, role), vals, role);                                           // (c^2)^x = t^(12x^3)
-  BN_OPAQUE(vals);
+  BN_OPAQUE_S(vals);
   const Fp6 e = tri_mul(tri_load(tri_val(vals, TV_B2), role), x, role);                      // e
   tri_store(tri_val(vals, TV_E), e, role);
   const Fp6 d = tri_mul(tri_load(tri_val(vals, TV_A), role), e, role);                       // d
   tri_store(tri_val(vals, TV_D), d, role);
   BN_MEM_FENCE;
   Fp6 r = tri_mul(tri_load(tri_val(vals, TV_C), role), e, role);
-  BN_OPAQUE(vals);
+  BN_OPAQUE_S(vals);
   r = tri_mul(tri_load(tri_val(vals, TV_T), role), r, role);                                 // l0 = t (c e)
   r = tri_mul(r, tri_frob<1>(tri_load(tri_val(vals, TV_D), role), role), role);
-  BN_OPAQUE(vals);
+  BN_OPAQUE_S(vals);
   r = tri_mul(r, tri_frob<2>(tri_load(tri_val(vals, TV_E), role), role), role);
-  BN_OPAQUE(vals);
+  BN_OPAQUE_S(vals);
   const Fp6 l3 = tri_mul(tri_conj(tri_load(tri_val(vals, TV_T), role), role), tri_load(tri_val(vals, TV_D), role), role);   // conj(t) d
   return tri_mul(r, tri_frob<3>(l3, role), role);
 }
