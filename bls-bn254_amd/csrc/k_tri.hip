@@ -44,7 +44,7 @@ BN_KERNEL k_fe_tri_hard(const int32_t* t_ws, size_t n, size_t stride, int32_t* v
   if (i >= n) return;
   const uint32_t role = tri_role();
   const Fp6 t = tri_load_canon(Ws{const_cast<int32_t*>(t_ws), stride, (uint32_t)i * 4u, true}, role);
-  const Fp6 r = tri_fe_hard(t, Ws{vals, n, (uint32_t)i * 4u, true, true}, role);       // vfold: twenty named values, see tower.h
+  const Fp6 r = tri_fe_hard(t, Ws{vals, n, (uint32_t)i * 4u, true}, role);
   const int half = tri_half_is_one(r, role) ? 1 : 0;
   const int h0 = __builtin_amdgcn_update_dpp(0, half, 0x00, 0xf, 0xf, false), h1 = __builtin_amdgcn_update_dpp(0, half, 0x55, 0xf, 0xf, false);
   const bool isone = (h0 & h1) != 0;

@@ -144,11 +144,8 @@ BN_FUNC Fp12 fp12_mul(const Fp12& a, const Fp12& b) {     // fp12.rs:203-210 val
 // `buf` selects buffer addressing for HBM workspaces on the device: the row base goes into a scalar buffer
 // descriptor and k * stride into the scalar offset, so no per-limb 64-bit address pair is ever formed in (or
 // spilled from) vector registers.  k * stride * 4 must stay below 4 GB (108 limbs x 4 M lanes: 1.8 GB).
-struct Ws { int32_t* base; size_t stride; uint32_t lane4; bool buf; bool vfold = false; };
-// vfold: limb k is addressed as (vector offset lane4 + k * stride * 4, scalar offset 0) instead of (lane4, scalar k * stride * 4).
-// One VALU add per access -- for kernels that touch so many named values that their scalar offsets do not fit the scalar
-// registers (k_fe_tri_hard: the compiler parked them in vector registers and wrapped every access in a read-first-lane loop).
-BN_INL Ws ws_at(const Ws& w, size_t limbs) { return {w.base + limbs * w.stride, w.stride, w.lane4, w.buf, w.vfold}; }
+struct Ws { int32_t* base; size_t stride; uint32_t lane4; bool buf; };
+BN_INL Ws ws_at(const Ws& w, size_t limbs) { return {w.base + limbs * w.stride, w.stride, w.lane4, w.buf}; }
 BN_INL int32_t* ws_addr(const Ws& w, int k) { return (int32_t*)((char*)(w.base + (size_t)k * w.stride) + w.lane4); }
 // The same reference with its base marked wave-uniform.  Buffer addressing keeps the base in scalar registers; a base that
 // reaches the load through the arguments of a REAL function (wide.h's noinline primitives) is not known to be uniform, and every
@@ -157,16 +154,13 @@ BN_INL Ws ws_uniform(const Ws& w) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const uint64_t b = (uint64_t)w.base;
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
-  return {(int32_t*)(((uint64_t)hi << 32) | lo), w.stride, w.lane4, w.buf, w.vfold};
+  return {(int32_t*)(((uint64_t)hi << 32) | lo), w.stride, w.lane4, w.buf};
 #else
   return w;
 #endif
 }
 BN_INL int32_t ws_load(const Ws& w, int k) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (w.buf && w.vfold)
-    return __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void*)w.base, 0, -1, 0x00020000),
-                                                (int)(w.lane4 + (uint32_t)((size_t)k * w.stride * 4)), 0, 0);
   if (w.buf)
     return __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void*)w.base, 0, -1, 0x00020000), (int)w.lane4,
                                                 (int)(uint32_t)((size_t)k * w.stride * 4), 0);
@@ -175,11 +169,6 @@ BN_INL int32_t ws_load(const Ws& w, int k) {
 }
 BN_INL void ws_store(const Ws& w, int k, int32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  if (w.buf && w.vfold) {
-    __builtin_amdgcn_raw_buffer_store_b32(v, __builtin_amdgcn_make_buffer_rsrc((void*)w.base, 0, -1, 0x00020000),
-                                          (int)(w.lane4 + (uint32_t)((size_t)k * w.stride * 4)), 0, 0);
-    return;
-  }
   if (w.buf) {
     __builtin_amdgcn_raw_buffer_store_b32(v, __builtin_amdgcn_make_buffer_rsrc((void*)w.base, 0, -1, 0x00020000), (int)w.lane4,
                                           (int)(uint32_t)((size_t)k * w.stride * 4), 0);

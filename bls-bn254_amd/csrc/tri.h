@@ -125,7 +125,7 @@ BN_INL uint32_t tri_arole(uint32_t role) { return role < 1u ? 0u : 1u; }
 // A workspace reference moved by a LANE-DEPENDENT number of limbs: the offset goes into the per-lane byte offset.  (ws_at moves
 // the base, which buffer addressing keeps in scalar registers: a base that differs between the lanes of a wave would have to be
 // serialised lane by lane.)  limbs * stride * 4 must fit 32 bits together with the lane's own offset.
-BN_INL Ws ws_at_lane(const Ws& w, uint32_t limbs) { return {w.base, w.stride, w.lane4 + limbs * (uint32_t)w.stride * 4u, w.buf, w.vfold}; }
+BN_INL Ws ws_at_lane(const Ws& w, uint32_t limbs) { return {w.base, w.stride, w.lane4 + limbs * (uint32_t)w.stride * 4u, w.buf}; }
 // canonical limbs: the exchange format with the one-lane-per-tuple kernels (f_ws, the easy part's output)
 BN_INL Fp6 tri_load_canon(const Ws& w, uint32_t role) {
   const Ws h = ws_at_lane(w, 54u * tri_arole(role));

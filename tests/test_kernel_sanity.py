@@ -38,3 +38,36 @@ def test_no_degenerate_kernels():
     assert len(kernels) >= 60, sorted(kernels)
     bad = [(k, v) for k, v in kernels.items() if v < 200 and not any(s in k for s in SMALL_OK)]
     assert not bad, "suspiciously small kernels (undefined behaviour in the source?): %s" % bad
+
+
+# The register-resident loops of the throughput path: built to fit the 512 registers of one wave per SIMD with NO spills to
+# memory (spills into the accumulation registers are part of the plan and do not count).  A header change that has nothing to
+# do with them can push them over (adding one bool to the workspace reference made k_fe_expx_h1 / _h2 spill 203 / 217 registers
+# to scratch: 4.65 -> 6.5 ms each, a 10 % slower step, with every test still green).  Limit = bytes of scratch per lane.
+SCRATCH_LIMIT = {"k_miller_prepared": 0, "k_fe_expx": 0, "k_fe_expx_h1": 0, "k_fe_expx_h2": 0, "k_fe_h3": 0, "k_fe_easy_tail": 0, "k_miller_tri_prepared": 0,
+                 "k_fe_tri_hard": 0, "k_miller_tri_1": 0, "k_miller_tri_1p": 0,
+                 "k_miller_wide_prepared": 64, "k_fe_hard_wide": 64}      # the wave-per-tuple kernels call real functions: a few stack words
+
+
+def test_throughput_kernels_do_not_spill_to_memory():
+    import blsbn254_loader
+    M = blsbn254_loader.load()
+    path = M.library_path()
+    if not os.path.exists(path):
+        __import__("bls_bn254_amd.build", fromlist=["x"]).build()
+    from kernel_resources import code_objects
+    tmp = tempfile.mkdtemp()
+    scratch = {}
+    for idx, (data, off, size) in enumerate(code_objects(path)):
+        co = os.path.join(tmp, "co_%d.o" % idx)
+        open(co, "wb").write(data[off:off + size])
+        notes = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+        for blk in notes.split("- .agpr_count:")[1:]:
+            name = re.search(r"\.name:\s*(\S+)", blk).group(1)
+            if name.startswith("_Z"):
+                name = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.split("(")[0].strip()
+            scratch[name] = int(re.search(r"\.private_segment_fixed_size:\s*(\d+)", blk).group(1))
+    missing = [k for k in SCRATCH_LIMIT if k not in scratch]
+    assert not missing, missing
+    bad = {k: scratch[k] for k, lim in SCRATCH_LIMIT.items() if scratch[k] > lim}
+    assert not bad, "scratch (spilled registers) in register-resident kernels, bytes per lane: %s" % bad
