@@ -138,8 +138,55 @@ BN_INL void tri_store_canon(const Ws& w, const Fp6& a, uint32_t role) {
   }
 }
 // normalised limbs as they are (no canonicalisation): the named values of the hard part
-BN_INL Fp6 tri_load(const Ws& w, uint32_t role) { return fp6_load_mem(ws_at_lane(w, 54u * tri_arole(role))); }
-BN_INL void tri_store(const Ws& w, const Fp6& a, uint32_t role) { if (role < 2u) fp6_store_mem(ws_at_lane(w, 54u * role), a); }
+// (all 54 limbs through ONE reference: fp6_load_mem would move the base once per Fp -- six buffer descriptors of four scalar
+// registers each per value, and with two or three values in flight the scalar file overflows into vector registers, whose
+// contents can only come back through a read-first-lane loop around every access)
+BN_INL Fp fp_load_mem_at(const Ws& w, int j) {                   // the j-th Fp (limbs 9 j .. 9 j + 8) behind w
+  Fp r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (w.buf) {                                                   // running VECTOR offset: no per-limb scalar offsets to keep (54 per value)
+    const uint32_t step = (uint32_t)w.stride * 4u;
+    uint32_t off = w.lane4 + 9u * (uint32_t)j * step;
+    BN_UNROLL for (int k = 0; k < NL; ++k) {
+      r.l[k] = __builtin_amdgcn_raw_buffer_load_b32(__builtin_amdgcn_make_buffer_rsrc((void*)w.base, 0, -1, 0x00020000), (int)off, 0, 0);
+      off += step;
+    }
+    return r;
+  }
+#endif
+  BN_UNROLL for (int k = 0; k < NL; ++k) r.l[k] = ws_load(w, 9 * j + k);
+  BN_TRK(ParkTrk pt; { std::lock_guard<std::mutex> g(park_mutex()); auto it = park_trk().find(ws_addr(w, 9 * j));
+           if (it == park_trk().end()) check_fail("fp_load_mem_at of an address never stored", 0); pt = it->second; }
+         set_trk(r, pt.lo, pt.hi, pt.tlo, pt.thi, pt.vb);)
+  return r;
+}
+BN_INL void fp_store_mem_at(const Ws& w, int j, const Fp& a) {
+  BN_TRK(if (a.lo < -4e-6 || a.hi > 1.0 + 4e-6) check_fail("fp_store_mem_at needs a normalised value", mag(a));
+         { std::lock_guard<std::mutex> g(park_mutex()); park_trk()[ws_addr(w, 9 * j)] = ParkTrk{a.lo, a.hi, a.tlo, a.thi, a.vb}; })
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (w.buf) {
+    const uint32_t step = (uint32_t)w.stride * 4u;
+    uint32_t off = w.lane4 + 9u * (uint32_t)j * step;
+    BN_UNROLL for (int k = 0; k < NL; ++k) {
+      __builtin_amdgcn_raw_buffer_store_b32(a.l[k], __builtin_amdgcn_make_buffer_rsrc((void*)w.base, 0, -1, 0x00020000), (int)off, 0, 0);
+      off += step;
+    }
+    return;
+  }
+#endif
+  BN_UNROLL for (int k = 0; k < NL; ++k) ws_store(w, 9 * j + k, a.l[k]);
+}
+BN_INL Fp6 tri_load(const Ws& w0, uint32_t role) {
+  const Ws w = ws_at_lane(w0, 54u * tri_arole(role));
+  return {{fp_load_mem_at(w, 0), fp_load_mem_at(w, 1)}, {fp_load_mem_at(w, 2), fp_load_mem_at(w, 3)}, {fp_load_mem_at(w, 4), fp_load_mem_at(w, 5)}};
+}
+BN_INL void tri_store(const Ws& w0, const Fp6& a, uint32_t role) {
+  if (role < 2u) {
+    const Ws w = ws_at_lane(w0, 54u * role);
+    fp_store_mem_at(w, 0, a.c0.c0); fp_store_mem_at(w, 1, a.c0.c1); fp_store_mem_at(w, 2, a.c1.c0); fp_store_mem_at(w, 3, a.c1.c1);
+    fp_store_mem_at(w, 4, a.c2.c0); fp_store_mem_at(w, 5, a.c2.c1);
+  }
+}
 // lane 0: c0 == 1, lane 1: c1 == 0; other lanes: true
 BN_INL bool tri_half_is_one(const Fp6& a, uint32_t role) {
   const bool z = fp_is_zero(fp_sub(a.c0.c0, fp_pick(role == 0u, fp_one(), fp_zero()))) & fp_is_zero(a.c0.c1) & fp2_is_zero(a.c1) & fp2_is_zero(a.c2);
