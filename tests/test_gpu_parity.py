@@ -1265,6 +1265,8 @@ def test_three_lanes_per_tuple_kernels_equal_lane_per_tuple(oracle, pyref, M, mo
     """k_tri.hip (three lanes per tuple: launches of 4097 ... 16384 tuples) == the lane-per-tuple kernels (BLSBN254_TRI_MAX=0) == the
     expectation: verify_batch on the prepared-key path (Miller loop + hard part on quads), the RLC path (its chunk and fallback
     rounds), and pairing_batch (the final exponentiation alone on quads, Gt bytes) at sizes around both switch-overs."""
+    if os.environ.get("BLSBN254_TRI_MAX", "16384") == "0":
+        pytest.skip("the three-lane kernels are switched off by the environment (BLSBN254_TRI_MAX=0): nothing to compare")
     dst = M.DEFAULT_DST
     e_tri = M.Engine(0)
     monkeypatch.setenv("BLSBN254_TRI_MAX", "0")
@@ -1312,6 +1314,8 @@ def test_aggregate_verify_mid_size_distinct_keys_on_quads(oracle, pyref, M, monk
     """aggregate_verify over a few thousand DISTINCT keys: every key is prepared (four lanes per key) and every pair runs on a quad
     of lanes off its key's table (k_miller_tri_1p), one product tree, one final exponentiation == the pairwise lane path
     (BLSBN254_TRI_MAX=0) == the expectation; tampered message, a key outside the subgroup."""
+    if os.environ.get("BLSBN254_TRI_MAX", "16384") == "0" or os.environ.get("BLSBN254_TRI_MILLER", "1") == "0" or os.environ.get("BLSBN254_QUAD_PREP", "1") == "0":
+        pytest.skip("the quad kernels are switched off by the environment (production knobs): nothing to compare")
     dst = M.DEFAULT_DST
     e_tri = M.Engine(0)
     monkeypatch.setenv("BLSBN254_TRI_MAX", "0")
@@ -1352,6 +1356,8 @@ def test_verify_batch_dev_asynchronous_path(oracle, M):
     blsbn254_ctx_synchronize.  Same bitmaps as the counting path: repeated calls, two calls in flight, a new domain-separation tag
     between calls, and the cases where the assumption FAILS and the call is re-run -- more keys than reserved, a key set that no
     longer repeats (exact path), then back to few keys."""
+    if os.environ.get("BLSBN254_ASYNC_VERIFY", "1") == "0":
+        pytest.skip("the optimistic path is switched off by the environment (BLSBN254_ASYNC_VERIFY=0)")
     import torch
     dst = M.DEFAULT_DST
     e = M.Engine(0)
