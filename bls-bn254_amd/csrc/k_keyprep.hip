@@ -147,12 +147,35 @@ BN_KERNEL k_g2_prepare(const uint8_t* pks, const uint32_t* keys, uint32_t u, int
 }
 // The pair tables: lane (key k, step t) multiplies the key's line t with the fixed -G2gen line t (pairing.h line_pair_expand):
 // raw (u x 88 x 54 limbs) -> expanded (u x 88 x 162 limbs).  u x 88 lanes: the part of the preparation that is not sequential.
+// A lane's entry is 648 consecutive bytes, so a lane-by-lane store instruction would touch 64 different cache lines with 4 bytes
+// each (the kernel was bound by exactly that: 233 MB of partial-line writes per 4096 keys).  The entries of a workgroup are one
+// contiguous block of 256 x 648 bytes: every product goes to LDS first ([lane][18 limbs]) and is written out by the workgroup
+// in runs of 18 consecutive dwords; the raw triples come in the same way.
 BN_KERNEL k_g2_expand(const int32_t* raw, uint32_t u, int32_t* expanded, const uint32_t* d_u) {
-  const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= u * (uint32_t)BN_NEG_G2_LINES || (d_u && e >= *d_u * (uint32_t)BN_NEG_G2_LINES)) return;
+  __shared__ int32_t stage[256 * 54];                       // the workgroup's raw triples, then one Fp2 product per lane at a time
+  const uint32_t e0 = blockIdx.x * blockDim.x, e = e0 + threadIdx.x;
+  uint32_t total = u * (uint32_t)BN_NEG_G2_LINES;
+  if (d_u && *d_u * (uint32_t)BN_NEG_G2_LINES < total) total = *d_u * (uint32_t)BN_NEG_G2_LINES;
+  if (e0 >= total) return;                                  // whole workgroups leave together (barriers below)
+  const uint32_t here = total - e0 < 256u ? total - e0 : 256u;
+  for (uint32_t x = threadIdx.x; x < here * 54u; x += 256u) stage[x] = raw[(size_t)e0 * 54u + x];      // coalesced: the block's triples are contiguous
+  __syncthreads();
+  const bool live = threadIdx.x < here;
   const uint32_t t = e % (uint32_t)BN_NEG_G2_LINES;
-  const Line b = line_load_limbs(Ws{const_cast<int32_t*>(raw), 1, e * (uint32_t)(54 * 4), true});
-  line_pair_expand(line_from_table(BN_NEG_G2_LINE_TABLE[t]), b, Ws{expanded, 1, e * (uint32_t)(162 * 4), true});
+  const Line a = line_from_table(BN_NEG_G2_LINE_TABLE[t]);
+  const Line b = line_load_limbs(Ws{stage, 1, (live ? threadIdx.x : 0u) * (uint32_t)(54 * 4), false});
+  __syncthreads();
+  BN_UNROLL for (int j = 0; j < 9; ++j) {                   // T0 .. T8 in the order of line_pair_expand
+    const Fp2 p = j == 0 ? fp2_mul(a.c0, b.c0) : j == 1 ? fp2_mul_xi(fp2_mul(a.c2, b.c2)) : j == 2 ? fp2_mul(a.c1, b.c1) : j == 3 ? fp2_mul(a.c1, b.c2)
+                : j == 4 ? fp2_mul(a.c2, b.c1) : j == 5 ? fp2_mul(a.c0, b.c1) : j == 6 ? fp2_mul(a.c1, b.c0) : j == 7 ? fp2_mul(a.c0, b.c2) : fp2_mul(a.c2, b.c0);
+    fp2_store_limbs_lazy(Ws{stage, 1, threadIdx.x * (uint32_t)(18 * 4), false}, p);
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < here * 18u; x += 256u) {
+      const uint32_t lane = x / 18u, limb = x - 18u * lane;
+      expanded[((size_t)e0 + lane) * 162u + 18u * (uint32_t)j + limb] = stage[x];
+    }
+    __syncthreads();
+  }
 }
 // valid (caller's order, one byte per tuple) from the key-sorted results: is_one[s] & flags[s] of sorted position s = perm^-1
 __global__ void k_prep_unsort(const uint8_t* is_one, const uint8_t* flags, const uint32_t* perm, uint32_t n, uint8_t* valid) {

@@ -616,17 +616,32 @@ BN_FUNC void g2_prepare_lines(const G2A& q, const Ws& out) {
 // A step then spends 1 scaling + 4 double products (2268 MADs) on the line pair instead of 4 scalings + 6 Fp2 products
 // (4212), and the 17-product sparse multiplication of f is unchanged.  The loop's value differs from the textbook product of
 // the two Miller values only by powers of Z (an element of Fp), which the final exponentiation removes: same bitmap.
+// Entries of the pair table are stored as the products come out of the multiplier (limbs 0..7 in [0, 2^29], a small signed top
+// limb, value within (1 + eps) p) -- NOT canonical: canonicalising 18 field elements per (key, step) was 45 % of k_g2_expand,
+// and the only readers are the double products of the line evaluation below (and of tri.h / wide.h), which take lazy operands.
+BN_INL void fp_store_limbs_lazy(const Ws& w, const Fp& c) {
+  BN_TRK(if (c.lo < -4e-6 || c.hi > 1.0 + 4e-6 || c.tlo < -0.02 || c.thi > 0.02 || c.vb > 1.2) check_fail("pair table entry outside its declared range", c.vb);)
+  BN_UNROLL for (int k = 0; k < NL; ++k) ws_store(w, k, c.l[k]);
+}
+BN_INL Fp fp_load_limbs_lazy(const Ws& w) {
+  Fp c;
+  BN_UNROLL for (int k = 0; k < NL; ++k) c.l[k] = ws_load(w, k);
+  BN_TRK(set_trk(c, -4e-6, 1.0 + 4e-6, -0.02, 0.02, 1.2); check_actual(c, "pair table entry");)
+  return c;
+}
+BN_INL void fp2_store_limbs_lazy(const Ws& w, const Fp2& c) { fp_store_limbs_lazy(w, c.c0); fp_store_limbs_lazy(ws_at(w, 9), c.c1); }
+BN_INL Fp2 fp2_load_limbs_lazy(const Ws& w) { return {fp_load_limbs_lazy(w), fp_load_limbs_lazy(ws_at(w, 9))}; }
 BN_FUNC void line_pair_expand(const Line& a, const Line& b, const Ws& out) {
   BN_CTX;
-  fp2_store_limbs(out, fp2_mul(a.c0, b.c0));
-  fp2_store_limbs(ws_at(out, 18), fp2_mul_xi(fp2_mul(a.c2, b.c2)));
-  fp2_store_limbs(ws_at(out, 36), fp2_mul(a.c1, b.c1));
-  fp2_store_limbs(ws_at(out, 54), fp2_mul(a.c1, b.c2));
-  fp2_store_limbs(ws_at(out, 72), fp2_mul(a.c2, b.c1));
-  fp2_store_limbs(ws_at(out, 90), fp2_mul(a.c0, b.c1));
-  fp2_store_limbs(ws_at(out, 108), fp2_mul(a.c1, b.c0));
-  fp2_store_limbs(ws_at(out, 126), fp2_mul(a.c0, b.c2));
-  fp2_store_limbs(ws_at(out, 144), fp2_mul(a.c2, b.c0));
+  fp2_store_limbs_lazy(out, fp2_mul(a.c0, b.c0));
+  fp2_store_limbs_lazy(ws_at(out, 18), fp2_mul_xi(fp2_mul(a.c2, b.c2)));
+  fp2_store_limbs_lazy(ws_at(out, 36), fp2_mul(a.c1, b.c1));
+  fp2_store_limbs_lazy(ws_at(out, 54), fp2_mul(a.c1, b.c2));
+  fp2_store_limbs_lazy(ws_at(out, 72), fp2_mul(a.c2, b.c1));
+  fp2_store_limbs_lazy(ws_at(out, 90), fp2_mul(a.c0, b.c1));
+  fp2_store_limbs_lazy(ws_at(out, 108), fp2_mul(a.c1, b.c0));
+  fp2_store_limbs_lazy(ws_at(out, 126), fp2_mul(a.c0, b.c2));
+  fp2_store_limbs_lazy(ws_at(out, 144), fp2_mul(a.c2, b.c0));
 }
 BN_INL Fp2 fp2_dot_fp(const Fp2& t, const Fp& s, const Fp2& u, const Fp& r) {      // t s + u r, one reduction per component
   return {fp_dot2(t.c0, s, u.c0, r), fp_dot2(t.c1, s, u.c1, r)};
@@ -640,11 +655,11 @@ BN_FUNC Fp12 ell_pair_expanded(const Fp12& f, const Ws& e, const Ws& cw) {
   Fp X = fp_load_mem(cw), Y = fp_load_mem(ws_at(cw, 9)), Z = fp_load_mem(ws_at(cw, 18));
   Fp xsX = fp_load_mem(ws_at(cw, 27)), ysY = fp_load_mem(ws_at(cw, 36)), xsZ = fp_load_mem(ws_at(cw, 45));
   Fp ysZ = fp_load_mem(ws_at(cw, 54)), ysX = fp_load_mem(ws_at(cw, 63)), xsY = fp_load_mem(ws_at(cw, 72));
-  Fp6 l0 = {fp2_dot_fp(fp2_load_limbs(e), ysY, fp2_load_limbs(ws_at(e, 18)), Z),
-            fp2_mul_fp(fp2_load_limbs(ws_at(e, 36)), xsX),
-            fp2_dot_fp(fp2_load_limbs(ws_at(e, 54)), xsZ, fp2_load_limbs(ws_at(e, 72)), X)};
-  Fp2 l10 = fp2_dot_fp(fp2_load_limbs(ws_at(e, 90)), ysX, fp2_load_limbs(ws_at(e, 108)), xsY);
-  Fp2 l11 = fp2_dot_fp(fp2_load_limbs(ws_at(e, 126)), ysZ, fp2_load_limbs(ws_at(e, 144)), Y);
+  Fp6 l0 = {fp2_dot_fp(fp2_load_limbs_lazy(e), ysY, fp2_load_limbs_lazy(ws_at(e, 18)), Z),
+            fp2_mul_fp(fp2_load_limbs_lazy(ws_at(e, 36)), xsX),
+            fp2_dot_fp(fp2_load_limbs_lazy(ws_at(e, 54)), xsZ, fp2_load_limbs_lazy(ws_at(e, 72)), X)};
+  Fp2 l10 = fp2_dot_fp(fp2_load_limbs_lazy(ws_at(e, 90)), ysX, fp2_load_limbs_lazy(ws_at(e, 108)), xsY);
+  Fp2 l11 = fp2_dot_fp(fp2_load_limbs_lazy(ws_at(e, 126)), ysZ, fp2_load_limbs_lazy(ws_at(e, 144)), Y);
   Fp6 v0 = fp6_mul(f.c0, l0);
   Fp6 v1 = fp6_mul_by_01(f.c1, l10, l11);
   Fp6 dl = {fp2_norm(fp2_sub(l10, l0.c0)), fp2_norm(fp2_sub(l11, l0.c1)), fp2_norm(fp2_neg(l0.c2))};       // l1 - l0

@@ -209,9 +209,9 @@ BN_FUNC Fp6 tri_line_pair(const Ws& e, const Ws& cw, uint32_t role) {
   const Fp s1b = fp_pick(odd, fp_load_mem(ws_at_lane(cw, 9u * cb1)), zero);
   const Fp s2a = fp_pick(odd, zero, fp_load_mem(ws_at_lane(cw, 9u * ca2))), s2b = fp_pick(odd, zero, fp_load_mem(ws_at_lane(cw, 9u * cb2)));
   Fp6 l;
-  l.c0 = fp2_dot_fp(fp2_load_limbs(ws_at_lane(e, 18u * ta0)), fp_load_mem(ws_at_lane(cw, 9u * ca0)), fp2_load_limbs(ws_at_lane(e, 18u * tb0)), fp_load_mem(ws_at_lane(cw, 9u * cb0)));
-  l.c1 = fp2_dot_fp(fp2_load_limbs(ws_at_lane(e, 18u * ta1)), fp_load_mem(ws_at_lane(cw, 9u * ca1)), fp2_load_limbs(ws_at_lane(e, 18u * tb1)), s1b);
-  l.c2 = fp2_dot_fp(fp2_load_limbs(ws_at_lane(e, 18u * ta2)), s2a, fp2_load_limbs(ws_at_lane(e, 18u * tb2)), s2b);
+  l.c0 = fp2_dot_fp(fp2_load_limbs_lazy(ws_at_lane(e, 18u * ta0)), fp_load_mem(ws_at_lane(cw, 9u * ca0)), fp2_load_limbs_lazy(ws_at_lane(e, 18u * tb0)), fp_load_mem(ws_at_lane(cw, 9u * cb0)));
+  l.c1 = fp2_dot_fp(fp2_load_limbs_lazy(ws_at_lane(e, 18u * ta1)), fp_load_mem(ws_at_lane(cw, 9u * ca1)), fp2_load_limbs_lazy(ws_at_lane(e, 18u * tb1)), s1b);
+  l.c2 = fp2_dot_fp(fp2_load_limbs_lazy(ws_at_lane(e, 18u * ta2)), s2a, fp2_load_limbs_lazy(ws_at_lane(e, 18u * tb2)), s2b);
   return l;                                                       // lane 0: l0, lane 1: l1 (c2 = 0); lanes 2, 3: l0's formulas (unused)
 }
 BN_FUNC Fp6 tri_miller_prepared(const Ws& cw, const Ws& ktab_in, uint32_t role) {

@@ -201,7 +201,7 @@ BN_FUNC void wide_mul_products_lines(const Wide& W, bool prod, uint32_t a, uint3
         if (mode == 0) {
           const uint32_t ia = sl == 0u ? 0u : sl == 1u ? 2u : sl == 2u ? 3u : sl == 3u ? 5u : 7u, ib = sl == 0u ? 1u : sl == 1u ? 2u : sl == 2u ? 4u : sl == 3u ? 6u : 8u;
           const uint32_t ca = sl == 0u ? 4u : sl == 1u ? 3u : sl == 2u ? 5u : sl == 3u ? 7u : 6u, cb = sl == 0u ? 2u : sl == 2u ? 0u : sl == 3u ? 8u : 1u;
-          a0 = fp_load_limbs_ws(ws_at_lane(tab, 162u * q + 18u * ia + 9u * h)); c0 = fp_load_limbs_ws(ws_at_lane(tab, 162u * q + 18u * ib + 9u * h));
+          a0 = fp_load_limbs_lazy(ws_at_lane(tab, 162u * q + 18u * ia + 9u * h)); c0 = fp_load_limbs_lazy(ws_at_lane(tab, 162u * q + 18u * ib + 9u * h));   // pair-table entries are lazy (pairing.h)
           b0 = fp_load_mem(ws_at_lane(cw, 9u * ca));
           d0 = fp_select(sl == 1u, fp_zero(), fp_load_mem(ws_at_lane(cw, 9u * cb)));      // T2 xsX stands alone
           used = sl < 5u;                                                                    // slot 5 (v^2 w) has no coefficient
