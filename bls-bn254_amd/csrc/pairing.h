@@ -630,7 +630,13 @@ BN_INL Fp fp_load_limbs_lazy(const Ws& w) {
   return c;
 }
 BN_INL void fp2_store_limbs_lazy(const Ws& w, const Fp2& c) { fp_store_limbs_lazy(w, c.c0); fp_store_limbs_lazy(ws_at(w, 9), c.c1); }
-BN_INL Fp2 fp2_load_limbs_lazy(const Ws& w) { return {fp_load_limbs_lazy(w), fp_load_limbs_lazy(ws_at(w, 9))}; }
+BN_INL Fp2 fp2_load_limbs_lazy(const Ws& w) {                    // both components through ONE reference, like fp2_load_limbs (a moved base is another buffer descriptor)
+  Fp2 c;
+  BN_UNROLL for (int k = 0; k < NL; ++k) { c.c0.l[k] = ws_load(w, k); c.c1.l[k] = ws_load(w, 9 + k); }
+  BN_TRK(set_trk(c.c0, -4e-6, 1.0 + 4e-6, -0.02, 0.02, 1.2); set_trk(c.c1, -4e-6, 1.0 + 4e-6, -0.02, 0.02, 1.2);
+         check_actual(c.c0, "pair table entry"); check_actual(c.c1, "pair table entry");)
+  return c;
+}
 BN_FUNC void line_pair_expand(const Line& a, const Line& b, const Ws& out) {
   BN_CTX;
   fp2_store_limbs_lazy(out, fp2_mul(a.c0, b.c0));
