@@ -71,3 +71,30 @@ def test_throughput_kernels_do_not_spill_to_memory():
     assert not missing, missing
     bad = {k: scratch[k] for k, lim in SCRATCH_LIMIT.items() if scratch[k] > lim}
     assert not bad, "scratch (spilled registers) in register-resident kernels, bytes per lane: %s" % bad
+
+
+# Serialised accesses: a buffer descriptor or scalar offset that reaches a load through VECTOR registers is wrapped in a
+# read-first-lane loop per access (k_fe_tri_hard had 1378 of them, the wave-per-tuple Miller loop paid 8.5 us per line value for
+# a lane-dependent base), and an LDS address that lost its address space becomes a flat access.  Limits per kernel:
+# (read-first-lane instructions, flat accesses); scripts/isa_lint.py prints the table for every kernel.
+SERIALISED_LIMITS = {"k_miller_prepared": (8, 0), "k_fe_expx": (8, 0), "k_fe_expx_h1": (8, 0), "k_fe_expx_h2": (8, 0), "k_fe_h3": (16, 0),
+                     "k_miller_tri_prepared": (16, 0), "k_fe_tri_hard": (100, 0), "k_miller_tri_1": (16, 0), "k_miller_tri_1p": (16, 0),
+                     "k_miller_wide_prepared": (100, 0), "k_fe_hard_wide": (300, 0), "k_hash_to_g1": (8, 0)}
+
+
+def test_hot_kernels_have_no_serialised_accesses():
+    import blsbn254_loader
+    M = blsbn254_loader.load()
+    path = M.library_path()
+    if not os.path.exists(path):
+        __import__("bls_bn254_amd.build", fromlist=["x"]).build()
+    from isa_lint import lint
+    found = {}
+    for sym, c in lint(path).items():
+        name = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.split("(")[0].strip() if sym.startswith("_Z") else sym
+        if name in SERIALISED_LIMITS:
+            found[name] = (c["readfirstlane"], c["flat"])
+    missing = [k for k in SERIALISED_LIMITS if k not in found]
+    assert not missing, missing
+    bad = {k: found[k] for k, (rfl, flat) in SERIALISED_LIMITS.items() if found[k][0] > rfl or found[k][1] > flat}
+    assert not bad, "read-first-lane instructions / flat accesses over the limit (kernel: (rfl, flat)): %s" % bad
