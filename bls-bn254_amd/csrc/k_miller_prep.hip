@@ -30,6 +30,16 @@ BN_KERNEL k_miller_prepared(const uint32_t* perm, const uint32_t* kid, const uin
   fp_store_mem(ws_at(inv, 54), fp_mul(ys, Z)); fp_store_mem(ws_at(inv, 63), fp_mul(ys, X)); fp_store_mem(ws_at(inv, 72), fp_mul(xs, Y));
   BN_MEM_FENCE;
   const Ws kt = {const_cast<int32_t*>(table), 1, k * (uint32_t)(BN_NEG_G2_LINES * 162 * 4), true};
+#ifdef BN_MILLER_UNIFORM_KEY
+  const uint32_t k0 = __builtin_amdgcn_readfirstlane(k);
+  Fp12 f;
+  if (__builtin_amdgcn_ballot_w64(k != k0) == 0)          // one key for the whole wave: its table through scalar loads
+    f = miller_loop_prepared_uniform(inv, table + (size_t)k0 * (BN_NEG_G2_LINES * 162));
+  else
+    f = miller_loop_prepared(inv, kt);
+  fp12_store_limbs(Ws{f_ws, n, s * 4u, true}, f);
+#else
   fp12_store_limbs(Ws{f_ws, n, s * 4u, true}, miller_loop_prepared(inv, kt));
+#endif
   flags[s] = (sig_ok && key_ok[k] != 0) ? 1 : 0;
 }

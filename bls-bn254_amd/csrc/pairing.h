@@ -695,6 +695,59 @@ BN_FUNC Fp12 miller_loop_prepared(const Ws& inv, const Ws& ktab_in) {
   }
   return f;
 }
+// The same loop when EVERY lane of the wave reads the same key's table (key-sorted order: the usual case): the entries are read
+// through a constant-address-space pointer with no per-lane part, i.e. by SCALAR loads into scalar registers -- no vector
+// registers held for them, the fetch runs ahead of the arithmetic -- and the double products take them as scalar operands.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) int32_t* bn_const_i32p;
+#else
+typedef const int32_t* bn_const_i32p;
+#endif
+BN_INL Fp2 fp2_load_limbs_const(bn_const_i32p e) {
+  Fp2 c;
+  BN_UNROLL for (int k = 0; k < NL; ++k) { c.c0.l[k] = e[k]; c.c1.l[k] = e[9 + k]; }
+  BN_TRK(set_trk(c.c0, -4e-6, 1.0 + 4e-6, -0.02, 0.02, 1.2); set_trk(c.c1, -4e-6, 1.0 + 4e-6, -0.02, 0.02, 1.2);
+         check_actual(c.c0, "pair table entry"); check_actual(c.c1, "pair table entry");)
+  return c;
+}
+BN_FUNC Fp12 ell_pair_expanded_uniform(const Fp12& f, bn_const_i32p e, const Ws& cw) {
+  Fp X = fp_load_mem(cw), Y = fp_load_mem(ws_at(cw, 9)), Z = fp_load_mem(ws_at(cw, 18));
+  Fp xsX = fp_load_mem(ws_at(cw, 27)), ysY = fp_load_mem(ws_at(cw, 36)), xsZ = fp_load_mem(ws_at(cw, 45));
+  Fp ysZ = fp_load_mem(ws_at(cw, 54)), ysX = fp_load_mem(ws_at(cw, 63)), xsY = fp_load_mem(ws_at(cw, 72));
+  Fp6 l0 = {fp2_dot_fp(fp2_load_limbs_const(e), ysY, fp2_load_limbs_const(e + 18), Z),
+            fp2_mul_fp(fp2_load_limbs_const(e + 36), xsX),
+            fp2_dot_fp(fp2_load_limbs_const(e + 54), xsZ, fp2_load_limbs_const(e + 72), X)};
+  Fp2 l10 = fp2_dot_fp(fp2_load_limbs_const(e + 90), ysX, fp2_load_limbs_const(e + 108), xsY);
+  Fp2 l11 = fp2_dot_fp(fp2_load_limbs_const(e + 126), ysZ, fp2_load_limbs_const(e + 144), Y);
+  Fp6 v0 = fp6_mul(f.c0, l0);
+  Fp6 v1 = fp6_mul_by_01(f.c1, l10, l11);
+  Fp6 dl = {fp2_norm(fp2_sub(l10, l0.c0)), fp2_norm(fp2_sub(l11, l0.c1)), fp2_norm(fp2_neg(l0.c2))};       // l1 - l0
+  Fp6 w = fp6_mul(fp6_norm(fp6_sub(f.c0, f.c1)), dl);
+  return {fp6_add_mul_v(v0, v1), fp6_norm(fp6_add(fp6_add(w, v0), v1))};
+}
+BN_FUNC Fp12 miller_loop_prepared_uniform(const Ws& inv, const int32_t* ktab_uniform) {
+  Fp12 f = fp12_one();
+  Ws p = inv;
+  bn_const_i32p kt = (bn_const_i32p)ktab_uniform;
+  int ti = 0;
+  for (int j = bnc::ATE_NAF_LEN - 2; j >= 0; --j) {
+    f = fp12_sqr(f);
+    BN_OPAQUE(p);
+    f = ell_pair_expanded_uniform(f, kt + 162 * ti, p);
+    ++ti;
+    if (ate_naf_digit(j) != 0) {
+      BN_OPAQUE(p);
+      f = ell_pair_expanded_uniform(f, kt + 162 * ti, p);
+      ++ti;
+    }
+  }
+  for (int e = 0; e < 2; ++e) {
+    BN_OPAQUE(p);
+    f = ell_pair_expanded_uniform(f, kt + 162 * ti, p);
+    ++ti;
+  }
+  return f;
+}
 
 // One pair per lane with a prepared key: f = ML(H, Q), the line triples of Q read from its raw table (88 x 54 limbs).  More work
 // per pair than the two-pairs-per-lane loop below (f^2 is not shared) but the shortest chain per lane: used when a launch has so
